@@ -1,0 +1,217 @@
+"""ORACLE (test infrastructure only) -- floating-point restatement of the DTI hot path.
+
+Functional CPU restatement of the reference's forward arithmetic, written with
+explicit tensors and weights (no nn.Module from the reference, no state).  Every
+function takes weights explicitly and works in whatever dtype the inputs carry,
+so the same code gives an fp32 oracle (the CPU baseline) and an fp64 oracle
+(the yard-stick for the 1e-5 tolerance).  Backward values come from autograd on
+these functions.  Follows:
+
+* GraphConvLayer.forward      /root/reference/jova/nn/layers.py:282-347
+* GraphPool.forward           /root/reference/jova/nn/layers.py:356-393
+* GraphGather2D.forward       /root/reference/jova/nn/layers.py:427-437
+* nonsat_activation           /root/reference/jova/nn/models.py:458-478
+* GraphConvSequential stack   /root/reference/proj/dti/train_joint_attn.py:155-174
+* Prot2Vec.forward            /root/reference/jova/nn/models.py:704-715
+* ProteinCNN2D.forward        /root/reference/jova/nn/models.py:768-771
+* JointAttention.forward      /root/reference/jova/nn/models.py:939-973
+* SegmentWiseResBlock         /root/reference/jova/nn/models.py:984-1018
+* integrated net + loss       /root/reference/proj/dti/train_joint_attn.py:188-243, :456-465
+
+Pinned against golden vectors exported from the imported reference
+(tests/golden/op_*.npz, e2e_*.npz; made by tools/make_golden.py).  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import math
+
+import torch
+
+BN_EPS = 1e-5
+LN_EPS = 1e-5
+
+
+def _as_long(t):
+    return t if t.dtype == torch.int64 else t.long()
+
+
+# ----------------------------------------------------------------------------- graph stack
+def graph_conv(atoms, deg_slice, adj_lists, weights, biases, relu=True, max_deg=10, out_dtype=None):
+    """layers.py:282-347.  weights/biases: 21 entries, order (rel_1, self_1, ..., rel_10, self_10, self_0)."""
+    dt = out_dtype or (weights[0].dtype)
+    pieces = [None] * (max_deg + 1)
+    for d in range(1, max_deg + 1):
+        adj = _as_long(adj_lists[d - 1])
+        begin, size = int(deg_slice[d, 0]), int(deg_slice[d, 1])
+        nbr_sum = atoms[adj].sum(dim=1)                              # :289-291 (exact in int64 for layer 1)
+        self_rows = atoms[begin:begin + size]
+        w_rel, w_self = weights[2 * (d - 1)], weights[2 * (d - 1) + 1]
+        b_rel, b_self = biases[2 * (d - 1)], biases[2 * (d - 1) + 1]
+        pieces[d] = (nbr_sum.to(dt) @ w_rel.t() + b_rel) + (self_rows.to(dt) @ w_self.t() + b_self)   # :322-324
+    begin, size = int(deg_slice[0, 0]), int(deg_slice[0, 1])
+    pieces[0] = atoms[begin:begin + size].to(dt) @ weights[20].t() + biases[20]     # :329-339
+    out = torch.cat(pieces, dim=0)                                   # :342
+    return torch.relu(out) if relu else out
+
+
+def graph_pool(atoms, deg_slice, adj_lists, max_deg=10):
+    """layers.py:356-393.  max over {self} U neighbours, first maximal index wins (self first)."""
+    pieces = []
+    begin, size = int(deg_slice[0, 0]), int(deg_slice[0, 1])
+    if size:
+        pieces.append(atoms[begin:begin + size])
+    for d in range(1, max_deg + 1):
+        begin, size = int(deg_slice[d, 0]), int(deg_slice[d, 1])
+        if size == 0:
+            continue
+        stacked = torch.cat([atoms[begin:begin + size].unsqueeze(1), atoms[_as_long(adj_lists[d - 1])]], dim=1)
+        pieces.append(stacked.max(dim=1)[0])
+    return torch.cat(pieces, dim=0)
+
+
+def gather2d(atoms, n_atoms_lst):
+    """layers.py:429-432: contiguous chunks of n_atoms rows, zero padded, stacked on dim 1 -> [A_max, B, g]."""
+    a_max = max(n_atoms_lst)
+    out = atoms.new_zeros((a_max, len(n_atoms_lst), atoms.shape[1]))
+    row = 0
+    for b, n in enumerate(n_atoms_lst):
+        out[:n, b, :] = atoms[row:row + n]
+        row += n
+    return out
+
+
+def nonsat(x, ep=1e-4, max_iter=100):
+    """models.py:458-478.  Returns (y, number of evaluations of the update).  Gradient only through the last one."""
+    y = x.detach().clone()
+    i = 0
+    while True:
+        y_new = (2. * y ** 3 / 3. + x) / (y ** 2 + 1.)
+        if float((y_new - y).detach().abs().mean()) <= ep or i > max_iter:
+            return y_new, i + 1
+        i += 1
+        y = y_new.detach()
+
+
+def batch_norm_train(x, gamma, beta, eps=BN_EPS):
+    """nn.BatchNorm1d in training mode over dim 0 (biased variance for the normalisation)."""
+    mean = x.mean(dim=0)
+    var = x.var(dim=0, unbiased=False)
+    return (x - mean) / torch.sqrt(var + eps) * gamma + beta
+
+
+def batch_norm_running(x, running_mean, running_var, momentum=0.1):
+    """Running-stat update of nn.BatchNorm1d (unbiased variance), for state-dict parity."""
+    n = x.shape[0]
+    mean = x.mean(dim=0)
+    var = x.var(dim=0, unbiased=True) if n > 1 else x.var(dim=0, unbiased=False)
+    return (1 - momentum) * running_mean + momentum * mean, (1 - momentum) * running_var + momentum * var
+
+
+def linear(x, w, b):
+    return x @ w.t() + b
+
+
+def gconv_net(glist, p, prefix=""):
+    """create_gconv_net, train_joint_attn.py:155-174 (dropout = identity: parity runs use dprob 0).
+
+    glist = [atoms, deg_slice, membership, n_atoms_lst, adj_1..adj_10]; p = state dict with the reference's keys
+    relative to the GraphConvSequential (``0.linear_layers.k.weight`` ...).  Returns ([A_max,B,g], nonsat evals)."""
+    atoms, deg_slice, n_atoms_lst, adj = glist[0], glist[1], glist[3], glist[4:]
+
+    def conv(x, idx):
+        w = [p["%s%d.linear_layers.%d.weight" % (prefix, idx, k)] for k in range(21)]
+        b = [p["%s%d.linear_layers.%d.bias" % (prefix, idx, k)] for k in range(21)]
+        return graph_conv(x, deg_slice, adj, w, b, relu=True)
+
+    def bn_relu(x, idx):
+        return torch.relu(batch_norm_train(x, p["%s%d.weight" % (prefix, idx)], p["%s%d.bias" % (prefix, idx)]))
+
+    x = conv(atoms, 0)
+    x = graph_pool(bn_relu(x, 1), deg_slice, adj)
+    x = conv(x, 4)
+    x = graph_pool(bn_relu(x, 5), deg_slice, adj)
+    x = linear(x, p[prefix + "8.weight"], p[prefix + "8.bias"])
+    x = bn_relu(x, 9)
+    return nonsat(gather2d(x, n_atoms_lst))
+
+
+# ----------------------------------------------------------------------------- protein branch
+def prot2vec(idx, emb_weight):
+    """models.py:710-715.  idx [B,P,w] -> relu(emb[idx]) reshaped [B,P,w*e] -> [P,B,w*e].  Pad row of emb is zero."""
+    e = emb_weight[idx]
+    e = torch.relu(e.reshape(idx.shape[0], idx.shape[1], -1))
+    return e.permute(1, 0, 2)
+
+
+def pcnn2d(x, weights, biases):
+    """models.py:768-771."""
+    for w, b in zip(weights, biases):
+        x = torch.relu(linear(x, w, b))
+    return x
+
+
+# ----------------------------------------------------------------------------- joint attention
+def layer_norm(x, gamma, beta, eps=LN_EPS):
+    mean = x.mean(dim=-1, keepdim=True)
+    var = x.var(dim=-1, unbiased=False, keepdim=True)
+    return (x - mean) / torch.sqrt(var + eps) * gamma + beta
+
+
+def mha_self(x, w_in, b_in, w_out, b_out, num_heads):
+    """nn.MultiheadAttention(x, x, x), no masks, dropout 0.  x [S,B,L]."""
+    s, b, l = x.shape
+    hd = l // num_heads
+    qkv = linear(x, w_in, b_in)
+    q, k, v = qkv[..., :l], qkv[..., l:2 * l], qkv[..., 2 * l:]
+    q = q * (1.0 / math.sqrt(hd))
+
+    def heads(t):
+        return t.reshape(s, b * num_heads, hd).transpose(0, 1)       # [B*H, S, hd]
+    attn = torch.softmax(heads(q) @ heads(k).transpose(1, 2), dim=-1)
+    o = (attn @ heads(v)).transpose(0, 1).reshape(s, b, l)
+    return linear(o, w_out, b_out), attn
+
+
+def joint_attention(inputs, p, num_heads, num_layers=1, prefix=""):
+    """models.py:939-973 with dprob 0.  inputs: list of [S_v,B,d_v]; returns [B, n_views*L]."""
+    num_segs = [t.shape[0] for t in inputs]
+    xs = [linear(t, p["%slin_prjs.%d.weight" % (prefix, i)], p["%slin_prjs.%d.bias" % (prefix, i)])
+          for i, t in enumerate(inputs)]
+    x = torch.cat(xs, dim=0)
+    for i in range(num_layers):
+        a = prefix + "attention_models.%d." % i
+        x_prime, _ = mha_self(x, p[a + "in_proj_weight"], p[a + "in_proj_bias"],
+                              p[a + "out_proj.weight"], p[a + "out_proj.bias"], num_heads)
+        x = layer_norm(x + x_prime, p[prefix + "attn_norm.weight"], p[prefix + "attn_norm.bias"])
+        r = prefix + "res_blks.%d." % i
+        h = torch.relu(linear(x, p[r + "seg_lin.linear1.weight"], p[r + "seg_lin.linear1.bias"]))
+        h = linear(h, p[r + "seg_lin.linear2.weight"], p[r + "seg_lin.linear2.bias"])
+        x = layer_norm(x + h, p[r + "normalize.weight"], p[r + "normalize.bias"])
+    pooled = [t.sum(dim=0) for t in torch.split(x, num_segs, dim=0)]
+    x = torch.cat(pooled, dim=1)
+    return torch.relu(batch_norm_train(x, p[prefix + "batch_norm.weight"], p[prefix + "batch_norm.bias"]))
+
+
+# ----------------------------------------------------------------------------- whole model
+def dti_forward(p, batch, num_heads, n_pcnn_layers, n_lin):
+    """create_integrated_net for views ecfp8-gconv__pcnn2d (train_joint_attn.py:188-243), dprob 0.
+
+    p: state dict with the reference's keys; batch: dict(ecfp [B,1024], glist, prot_idx [B,P,w]).
+    Returns (outputs [B,1], nonsat evaluations)."""
+    v_ecfp = batch["ecfp"].unsqueeze(0)
+    v_gconv, n_eval = gconv_net(batch["glist"], p, prefix="0.models.1.0.")
+    v_prot = prot2vec(batch["prot_idx"], p["0.models.2.0.embedding.weight"])
+    v_prot = pcnn2d(v_prot,
+                    [p["0.models.2.1.lin_kernels.%d.weight" % i] for i in range(n_pcnn_layers)],
+                    [p["0.models.2.1.lin_kernels.%d.bias" % i] for i in range(n_pcnn_layers)])
+    x = joint_attention([v_ecfp, v_gconv, v_prot], p, num_heads, prefix="1.")
+    k = 2
+    for _ in range(n_lin):
+        x = linear(x, p["%d.weight" % k], p["%d.bias" % k])
+        x = torch.relu(batch_norm_train(x, p["%d.weight" % (k + 1)], p["%d.bias" % (k + 1)]))
+        k += 4
+    return linear(x, p["%d.weight" % k], p["%d.bias" % k]), n_eval
+
+
+def mse_loss(outputs, weights, target):
+    """train_joint_attn.py:464-465."""
+    return ((outputs * weights - target) ** 2).mean()
