@@ -182,7 +182,10 @@ def test_e2e_step(dtype):
                 g = g.clone()
                 g[hp["vocab"]] = 0
             new = p[name].detach() - hp["lr"] * (g + hp["wd"] * p[name].detach())
-            H.assert_close(new, z[k], tol=1e-5, what=k, floor=hp["lr"] * floor)
+            # update error = weight rounding (1e-6 of the weights) + lr * gradient error (bound used above)
+            gmax = max(float(np.abs(z["step0.grad." + name]).max()), floor)
+            bound = 1e-6 * float(np.abs(z[k]).max()) + hp["lr"] * 5e-4 * gmax
+            assert float(np.abs(new.numpy() - z[k]).max()) <= bound, k
 
 
 def test_manifest_matches_survey():
