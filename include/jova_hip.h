@@ -1,0 +1,145 @@
+/* jova_hip.h -- C ABI of libjova_hip.so: the MI355X (gfx950) kernels behind the JOVA multi-view DTI training hot path.
+ *
+ * The reference (bbrighttaer/jova) has no FFI: its hot path is stock torch ops called from the nn.Modules of
+ * jova/nn/{layers,models}.py.  Each entry point below replaces the torch-op sequence of one of those modules
+ * (cited as file:line relative to the reference root); jova_amd/nn binds them with ctypes and keeps the
+ * reference's module names, constructor / forward signatures and state-dict keys.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its comment says "host"; tensors are dense row-major fp32 unless typed
+ *   - `stream` is a hipStream_t (0 = default stream); every call only enqueues work: no allocation, no sync
+ *   - return value 0 = ok, non-zero = error (jova_last_error() holds the message for the calling thread)
+ *   - "accumulates" = adds into the destination (parameter gradients), everything else overwrites
+ */
+#ifndef JOVA_HIP_H
+#define JOVA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JOVA_HIP_ABI_VERSION 1
+
+const char* jova_last_error(void);
+int jova_abi_version(void);
+
+/* ---- GraphConvLayer: jova/nn/layers.py:282-347 ---------------------------------------------------------------
+ * atoms [N, f_in] (int64 when atoms_is_i64, the featuriser's dtype for layer 1; else fp32), sorted degree-major as
+ * ConvMol.agglomerate_mols leaves them (jova/feat/mol_graphs.py:290-296); deg_slice int64 [11,2] (start,size);
+ * adj: HOST array of 10 device pointers, adj[d-1] = int32 [n_d, d]; weight/bias: HOST arrays of 21 device pointers
+ * in linear_layers order (rel_1, self_1, ..., rel_10, self_10, self_0), weight[k] = [f_out, f_in].
+ * out [N, f_out] = act( W_rel[d] . sum_nbr x + b_rel[d] + W_self[d] . x + b_self[d] ).
+ * bn_stats (optional, fp64 [2, f_out]): column sum / sum of squares of `out` for the BatchNorm1d that follows. */
+int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t n_atoms, int f_in, int f_out,
+                       const int64_t* deg_slice, const int32_t* const* adj, const float* const* weight,
+                       const float* const* bias, int relu, float* out, double* bn_stats, void* stream);
+
+/* Backward of the above.  dy [N, f_out]; y = forward output when the layer applied ReLU (mask), else NULL.
+ * dweight/dbias: HOST arrays of 21 device pointers, accumulate.  dx [N, f_in] (optional, fp32 atoms only) needs
+ * gbuf [N, f_in] scratch and `weight`.  sym_flag: device int from jova_adj_symmetry (NULL or 0 -> atomic scatter). */
+int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t n_atoms, int f_in, int f_out,
+                       const int64_t* deg_slice, const int32_t* const* adj, const float* const* weight,
+                       const float* dy, const float* y_or_null, float* const* dweight, float* const* dbias,
+                       float* dx_or_null, float* gbuf_or_null, const int* sym_flag, void* stream);
+
+/* *flag <- 1 iff the adjacency is a simple undirected graph (no self loops / duplicates, i in nbr(j) <=> j in nbr(i)):
+ * then the backward scatters above and below run as gathers.  Always true for ConvMol bond graphs. */
+int jova_adj_symmetry(int64_t n_atoms, const int64_t* deg_slice, const int32_t* const* adj, int* flag, void* stream);
+
+/* ---- GraphPool: jova/nn/layers.py:356-393 -------------------------------------------------------------------
+ * out[i] = max(x[i], max over neighbours); ties -> first candidate (self, then adjacency order) like torch.max.
+ * argmax uint8 [N, f]: 0 = self, k = k-th neighbour. */
+int jova_graphpool_fwd(const float* x, int64_t n_atoms, int f, const int64_t* deg_slice, const int32_t* const* adj,
+                       float* out, uint8_t* argmax, void* stream);
+int jova_graphpool_bwd(const float* dy, const uint8_t* argmax, int64_t n_atoms, int f, const int64_t* deg_slice,
+                       const int32_t* const* adj, float* dx, const int* sym_flag, int reserved, void* stream);
+
+/* ---- GraphGather2D: jova/nn/layers.py:427-437 ---------------------------------------------------------------
+ * mol_off int32 [batch+1] = prefix sums of n_atoms_lst; out [a_max, batch, g] = zero-padded contiguous chunks. */
+int jova_gather2d_fwd(const float* x, const int32_t* mol_off, int a_max, int batch, int g, float* out, void* stream);
+int jova_gather2d_bwd(const float* dout, const int32_t* mol_off, int a_max, int batch, int g, float* dx, void* stream);
+
+/* ---- nonsat_activation: jova/nn/models.py:458-478 -----------------------------------------------------------
+ * Newton-style iteration whose trip count depends on a global mean; decided on the device in ONE launch.
+ * out = y_final, dfac = d y_final / d x (= 1 / (y_prev^2 + 1)), n_eval_dev int32 [3] = (evaluations, arrivals,
+ * timeout flag).  workspace: jova_nonsat_workspace_bytes(n) bytes.  Backward: dx = dout * dfac (jova_mul). */
+size_t jova_nonsat_workspace_bytes(int64_t n);
+int jova_nonsat_fwd(const float* x, int64_t n, float ep, int max_iter, float* out, float* dfac, int* n_eval_dev,
+                    void* workspace, void* stream);
+int jova_mul(const float* a, const float* b, int64_t n, float* out, void* stream);
+
+/* ---- dense contractions: nn.Linear / bmm call sites of jova/nn/models.py:740-771, :944-963, :996-998 and
+ * proj/dti/train_joint_attn.py:167,229-238 -------------------------------------------------------------------
+ * C[z](m,n) = epi(alpha * sum_k A[z](m,k) B[z](k,n)), A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn] (one unit
+ * stride each), epi: + bias[n], + residual[m*ldr+n], ReLU.  splitk > 1: partial sums ADDED to C with atomics
+ * (no residual / relu).  Batch z = z1*nb2 + z2, offsets z1*s?1 + z2*s?2 (residual shares C's batch strides). */
+int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
+                  int64_t ldc, int M, int N, int K, float alpha, const float* bias, const float* residual, int64_t ldr,
+                  int relu, int splitk, int nb1, int nb2, int64_t sA1, int64_t sA2, int64_t sB1, int64_t sB2,
+                  int64_t sC1, int64_t sC2, void* stream);
+
+/* ---- nn.BatchNorm1d (training mode) call sites: proj/dti/train_joint_attn.py:158,163,168,232; models.py:926,972
+ * stats fp64 [2,c] from jova_colstats (or from jova_graphconv_fwd's fused epilogue). */
+int jova_colstats(const float* x, int64_t n_rows, int c, double* stats, void* stream);
+int jova_batchnorm_fwd(const float* x, int64_t n_rows, int c, const double* stats, const float* gamma,
+                       const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                       int64_t* num_batches, int relu, float* y, float* mean_rstd, void* stream);
+/* y = forward output when ReLU was fused (mask), else NULL; dgamma/dbeta accumulate; sums_ws fp64 [2,c] scratch */
+int jova_batchnorm_bwd(const float* x, const float* dy, const float* y_or_null, const float* mean_rstd,
+                       const float* gamma, int64_t n_rows, int c, float* dx, float* dgamma, float* dbeta,
+                       double* sums_ws, void* stream);
+/* out[c] += column sums of x [n_rows, c] (bias gradients) */
+int jova_colsum_add(const float* x, int64_t n_rows, int c, int64_t ld, float* out, void* stream);
+
+/* ---- nn.LayerNorm with fused residual add: jova/nn/models.py:959-960, :1016-1017 ----------------------------- */
+int jova_layernorm_fwd(const float* x, const float* residual_or_null, const float* gamma, const float* beta,
+                       int64_t n_rows, int d, float eps, float* y, float* mean_rstd, void* stream);
+/* dz = gradient w.r.t. (x + residual); dgamma/dbeta accumulate */
+int jova_layernorm_bwd(const float* x, const float* residual_or_null, const float* dy, const float* gamma,
+                       const float* mean_rstd, int64_t n_rows, int d, float* dz, float* dgamma, float* dbeta,
+                       void* stream);
+
+/* ---- softmax / dropout of nn.MultiheadAttention (jova/nn/models.py:952) and nn.Dropout ------------------------ */
+int jova_softmax_fwd(const float* x, int64_t n_rows, int n, int64_t ld, float* y, void* stream);
+int jova_softmax_bwd(const float* p, const float* dp, int64_t n_rows, int n, int64_t ld, float* ds, void* stream);
+/* y = x * keep / (1-p); keep is a pure function of (seed, offset, element index): call again on dy for backward */
+int jova_dropout(const float* x, int64_t n_rows, int n, int64_t ld, float p, uint64_t seed, uint64_t offset, float* y,
+                 void* stream);
+
+/* ---- Prot2Vec: jova/nn/models.py:214-242 (_construct_embedding_indices) + :704-715 ---------------------------
+ * table int32 [rows, window]: every protein profile, resident; prot_off/prot_len int32 [batch]: first row / segment
+ * count of each pair's protein.  out [p_max, batch, window*e] = act(E[idx]); idx_out (optional) int64
+ * [batch, p_max, window] = the reference's padded index cube (pad = vocab). */
+int jova_prot2vec_fwd(const int32_t* table, const int32_t* prot_off, const int32_t* prot_len, const float* emb,
+                      int batch, int p_max, int window, int e, int vocab, int relu, float* out,
+                      int64_t* idx_out_or_null, void* stream);
+/* demb [vocab+1, e] accumulates; the pad row receives nothing */
+int jova_prot2vec_bwd(const int32_t* table, const int32_t* prot_off, const int32_t* prot_len, const float* dout,
+                      const float* out, int batch, int p_max, int window, int e, int vocab, int relu, float* demb,
+                      void* stream);
+
+/* ---- JointAttention view pooling: jova/nn/models.py:966-971 ---------------------------------------------------
+ * x [S, batch, l]; seg_off int32 [n_views+1]; out [batch, n_views*l] */
+int jova_viewpool_fwd(const float* x, const int32_t* seg_off, int n_views, int batch, int l, float* out, void* stream);
+int jova_viewpool_bwd(const float* dout, const int32_t* seg_off, int n_views, int batch, int l, int s_total, float* dx,
+                      void* stream);
+
+/* ---- loss and optimiser step: proj/dti/train_joint_attn.py:464-465, :485-486 ---------------------------------- */
+int jova_mse_loss(const float* outputs, const float* weights, const float* target, int n, float* loss,
+                  float* dout_or_null, void* stream);
+int jova_sgd_step(float* params, const float* grads, float* momentum_buf_or_null, int64_t n, float lr,
+                  float weight_decay, float momentum, float grad_scale, int first_step, void* stream);
+int jova_adamax_step(float* params, const float* grads, float* exp_avg, float* exp_inf, int64_t n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, float grad_scale, int step, void* stream);
+
+/* ---- element-wise helpers (nn.ReLU and gradient bookkeeping) --------------------------------------------------- */
+int jova_relu_fwd(const float* x, int64_t n, float* y, void* stream);
+int jova_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* stream);
+int jova_axpy(const float* x, float a, int64_t n, float* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JOVA_HIP_H */

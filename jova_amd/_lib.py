@@ -1,0 +1,105 @@
+"""ctypes binding of libjova_hip.so (the C ABI declared in include/jova_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the shared library is missing or an entry point fails,
+the call raises.  PyTorch only supplies device memory (tensors) and the HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjova_hip.so")
+
+# signature codes: p = pointer, i = int, q = int64, f = float, Q = uint64
+_SIGS = {
+    "jova_graphconv_fwd": "piqiipppp" + "ippp",
+    "jova_graphconv_bwd": "piqiippp" + "pppp" + "pppp",
+    "jova_adj_symmetry": "qpppp",
+    "jova_graphpool_fwd": "pqipp" + "ppp",
+    "jova_graphpool_bwd": "ppqipp" + "ppip",
+    "jova_gather2d_fwd": "ppiiipp",
+    "jova_gather2d_bwd": "ppiiipp",
+    "jova_nonsat_fwd": "pqfipppp" + "p",
+    "jova_mul": "ppqpp",
+    "jova_gemm_f32": "pqqpqqpq" + "iiif" + "ppqii" + "ii" + "qqqqqq" + "p",
+    "jova_colstats": "pqipp",
+    "jova_batchnorm_fwd": "pqippp" + "ff" + "ppp" + "ippp",
+    "jova_batchnorm_bwd": "ppppp" + "qi" + "ppp" + "pp",
+    "jova_colsum_add": "pqiqpp",
+    "jova_layernorm_fwd": "pppp" + "qif" + "ppp",
+    "jova_layernorm_bwd": "ppppp" + "qi" + "pppp",
+    "jova_softmax_fwd": "pqiqpp",
+    "jova_softmax_bwd": "ppqiqpp",
+    "jova_dropout": "pqiqfQQpp",
+    "jova_prot2vec_fwd": "pppp" + "iiiiii" + "ppp",
+    "jova_prot2vec_bwd": "ppppp" + "iiiiii" + "pp",
+    "jova_viewpool_fwd": "ppiiipp",
+    "jova_viewpool_bwd": "ppiiiipp",
+    "jova_mse_loss": "pppippp",
+    "jova_sgd_step": "pppq" + "ffffi" + "p",
+    "jova_adamax_step": "ppppq" + "ffffffi" + "p",
+    "jova_relu_fwd": "pqpp",
+    "jova_relu_bwd": "ppqpp",
+    "jova_axpy": "pfqpp",
+}
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "q": ctypes.c_int64, "f": ctypes.c_float, "Q": ctypes.c_uint64}
+
+EXPORTS = sorted(list(_SIGS) + ["jova_last_error", "jova_abi_version", "jova_nonsat_workspace_bytes"])
+
+_lib = None
+
+
+def lib():
+    """Loads the shared library once; raises if it has not been built (``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("jova_amd: %s is missing -- build it with `make -C jova_amd/csrc` "
+                               "(there is no CPU fallback for the HIP path)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, sig in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = [_CT[c] for c in sig]
+            fn.restype = ctypes.c_int
+        L.jova_last_error.restype = ctypes.c_char_p
+        L.jova_last_error.argtypes = []
+        L.jova_abi_version.restype = ctypes.c_int
+        L.jova_nonsat_workspace_bytes.restype = ctypes.c_size_t
+        L.jova_nonsat_workspace_bytes.argtypes = [ctypes.c_int64]
+        _lib = L
+    return _lib
+
+
+def call(name, *args):
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, L.jova_last_error().decode()))
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def P(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous and live on the GPU."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "jova_amd kernels take contiguous GPU tensors"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors, n=None):
+    """Host array of device pointers (the `const T* const*` arguments of the ABI)."""
+    n = len(tensors) if n is None else n
+    arr = (ctypes.c_void_p * n)()
+    for k, t in enumerate(tensors):
+        arr[k] = None if t is None else t.data_ptr()
+    return arr
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and torch.is_tensor(t) and not t.is_cuda:
+            raise RuntimeError("jova_amd: tensors must live on the GPU (the HIP path has no CPU fallback)")

@@ -1,0 +1,262 @@
+// Protein embedding (Prot2Vec), view pooling, loss, optimiser and small element-wise kernels, gfx950.
+#include "common.h"
+#include "jova_hip.h"
+
+// ------------------------------------------------------------------------------------------------ Prot2Vec
+// The padded index cube [B, P_max, w] of the reference (jova/nn/models.py:233-242) is never materialised: all
+// protein profiles stay resident in HBM as one int32 table [rows, w]; a batch is (row offset, segment count) per
+// pair and the pad index (= vocab, the zero row of the embedding) is implied for p >= count.
+//   out[p][b][j*e + c] = relu(E[idx(b,p,j)][c])
+__global__ void prot2vec_fwd_kernel(const int* __restrict__ table, const int* __restrict__ prot_off,
+                                    const int* __restrict__ prot_len, const float* __restrict__ emb, int bsz,
+                                    int p_max, int w, int e, int vocab, int relu, float* __restrict__ out,
+                                    long long* __restrict__ idx_out) {
+    const long long total = (long long)p_max * bsz * w * e;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % e);
+        long long q = t / e;
+        const int j = (int)(q % w);
+        q /= w;
+        const int b = (int)(q % bsz), p = (int)(q / bsz);
+        int idx = vocab;
+        if (p < prot_len[b]) idx = table[((long long)prot_off[b] + p) * w + j];
+        idx = min(max(idx, 0), vocab);
+        float v = emb[(long long)idx * e + c];
+        if (relu) v = fmaxf(v, 0.f);
+        out[t] = v;
+        if (idx_out && c == 0) idx_out[((long long)b * p_max + p) * w + j] = idx;
+    }
+}
+
+// dE[idx][c] += dout * (out > 0); the pad row receives nothing (nn.Embedding padding_idx)
+__global__ void prot2vec_bwd_kernel(const int* __restrict__ table, const int* __restrict__ prot_off,
+                                    const int* __restrict__ prot_len, const float* __restrict__ dout,
+                                    const float* __restrict__ out, int bsz, int p_max, int w, int e, int vocab,
+                                    int relu, float* __restrict__ demb) {
+    const long long total = (long long)p_max * bsz * w * e;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % e);
+        long long q = t / e;
+        const int j = (int)(q % w);
+        q /= w;
+        const int b = (int)(q % bsz), p = (int)(q / bsz);
+        if (p >= prot_len[b]) continue;
+        int idx = table[((long long)prot_off[b] + p) * w + j];
+        if (idx < 0 || idx >= vocab) continue;
+        if (relu && !(out[t] > 0.f)) continue;
+        atomicAdd(&demb[(long long)idx * e + c], dout[t]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ view pooling
+// x [S, B, L] with views occupying consecutive segment ranges seg_off[v] .. seg_off[v+1]:
+//   out[b][v*L + c] = sum_{s in view v} x[s][b][c]          (JointAttention: split + sum(0) + cat, models.py:966-971)
+__global__ void viewpool_fwd_kernel(const float* __restrict__ x, const int* __restrict__ seg_off, int n_views, int bsz,
+                                    int l, float* __restrict__ out) {
+    const long long total = (long long)bsz * n_views * l;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c = (int)(t % l);
+    const int v = (int)((t / l) % n_views);
+    const int b = (int)(t / ((long long)l * n_views));
+    float s = 0.f;
+    for (int sgm = seg_off[v]; sgm < seg_off[v + 1]; ++sgm) s += x[((long long)sgm * bsz + b) * l + c];
+    out[t] = s;
+}
+
+__global__ void viewpool_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ seg_off, int n_views,
+                                    int bsz, int l, int s_total, float* __restrict__ dx) {
+    const long long total = (long long)s_total * bsz * l;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % l);
+        const int b = (int)((t / l) % bsz);
+        const int sgm = (int)(t / ((long long)l * bsz));
+        int v = 0;
+        for (int k = 1; k < n_views; ++k) v += (sgm >= seg_off[k]);
+        dx[t] = dout[((long long)b * n_views + v) * l + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ loss
+// loss = mean((out * w - y)^2) over n elements (nn.MSELoss on outputs*weights, train_joint_attn.py:464-465);
+// dout = 2 * w * (out * w - y) / n.  Single workgroup: n is the batch size.
+__global__ void __launch_bounds__(256)
+mse_kernel(const float* __restrict__ o, const float* __restrict__ w, const float* __restrict__ y, int n,
+           float* __restrict__ loss, float* __restrict__ dout) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float d = o[i] * w[i] - y[i];
+        acc += (double)d * d;
+        if (dout) dout[i] = 2.f * w[i] * d / (float)n;
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)n);
+}
+
+// ------------------------------------------------------------------------------------------------ optimiser
+// torch.optim.SGD(lr, momentum, weight_decay, nesterov=False): g += wd * p; buf = mu * buf + g; p -= lr * buf
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom, long long n,
+                           float lr, float wd, float mu, float gscale, int first) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+         e += (long long)gridDim.x * blockDim.x) {
+        float d = g[e] * gscale + wd * p[e];
+        if (mom) {
+            d = first ? d : mu * mom[e] + d;
+            mom[e] = d;
+        }
+        p[e] -= lr * d;
+    }
+}
+
+// torch.optim.Adamax(lr, betas, eps, weight_decay): the reference's default optimiser when no tuned CSV is found
+__global__ void adamax_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                              float* __restrict__ u, long long n, float lr, float b1, float b2, float eps, float wd,
+                              float gscale, float bias_corr1) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+         e += (long long)gridDim.x * blockDim.x) {
+        const float d = g[e] * gscale + wd * p[e];
+        const float mm = b1 * m[e] + (1.f - b1) * d;
+        const float uu = fmaxf(b2 * u[e], fabsf(d) + eps);
+        m[e] = mm;
+        u[e] = uu;
+        p[e] -= (lr / bias_corr1) * mm / uu;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ element-wise
+__global__ void relu_fwd_kernel(const float* __restrict__ x, long long n, float* __restrict__ y) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+        y[e] = fmaxf(x[e], 0.f);
+}
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, long long n,
+                                float* __restrict__ dx) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+        dx[e] = y[e] > 0.f ? dy[e] : 0.f;
+}
+__global__ void axpy_kernel(const float* __restrict__ x, float a, long long n, float* __restrict__ y) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+        y[e] += a * x[e];
+}
+
+static inline int ew_blocks(long long n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
+
+// ================================================================================================ C ABI
+extern "C" int jova_prot2vec_fwd(const int32_t* table, const int32_t* prot_off, const int32_t* prot_len,
+                                 const float* emb, int batch, int p_max, int window, int e, int vocab, int relu,
+                                 float* out, int64_t* idx_out_or_null, void* stream) {
+    JOVA_CHECK_ARG(table && prot_off && prot_len && emb && out, "prot2vec_fwd: null pointer");
+    JOVA_CHECK_ARG(batch >= 1 && p_max >= 0 && window >= 1 && e >= 1 && vocab >= 1, "prot2vec_fwd: bad shape");
+    const long long total = (long long)p_max * batch * window * e;
+    if (total == 0) return JOVA_OK;
+    hipLaunchKernelGGL(prot2vec_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, table, prot_off,
+                       prot_len, emb, batch, p_max, window, e, vocab, relu, out, (long long*)idx_out_or_null);
+    JOVA_CHECK_LAUNCH("prot2vec_fwd");
+    return JOVA_OK;
+}
+
+extern "C" int jova_prot2vec_bwd(const int32_t* table, const int32_t* prot_off, const int32_t* prot_len,
+                                 const float* dout, const float* out, int batch, int p_max, int window, int e,
+                                 int vocab, int relu, float* demb, void* stream) {
+    JOVA_CHECK_ARG(table && prot_off && prot_len && dout && out && demb, "prot2vec_bwd: null pointer");
+    JOVA_CHECK_ARG(batch >= 1 && p_max >= 0 && window >= 1 && e >= 1 && vocab >= 1, "prot2vec_bwd: bad shape");
+    const long long total = (long long)p_max * batch * window * e;
+    if (total == 0) return JOVA_OK;
+    hipLaunchKernelGGL(prot2vec_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, table, prot_off,
+                       prot_len, dout, out, batch, p_max, window, e, vocab, relu, demb);
+    JOVA_CHECK_LAUNCH("prot2vec_bwd");
+    return JOVA_OK;
+}
+
+extern "C" int jova_viewpool_fwd(const float* x, const int32_t* seg_off, int n_views, int batch, int l, float* out,
+                                 void* stream) {
+    JOVA_CHECK_ARG(x && seg_off && out && n_views >= 1 && batch >= 1 && l >= 1, "viewpool_fwd: bad argument");
+    const long long total = (long long)batch * n_views * l;
+    hipLaunchKernelGGL(viewpool_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, seg_off,
+                       n_views, batch, l, out);
+    JOVA_CHECK_LAUNCH("viewpool_fwd");
+    return JOVA_OK;
+}
+
+extern "C" int jova_viewpool_bwd(const float* dout, const int32_t* seg_off, int n_views, int batch, int l,
+                                 int s_total, float* dx, void* stream) {
+    JOVA_CHECK_ARG(dout && seg_off && dx && n_views >= 1 && batch >= 1 && l >= 1 && s_total >= 0, "viewpool_bwd: bad argument");
+    const long long total = (long long)s_total * batch * l;
+    if (total == 0) return JOVA_OK;
+    hipLaunchKernelGGL(viewpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dout, seg_off,
+                       n_views, batch, l, s_total, dx);
+    JOVA_CHECK_LAUNCH("viewpool_bwd");
+    return JOVA_OK;
+}
+
+extern "C" int jova_mse_loss(const float* outputs, const float* weights, const float* target, int n, float* loss,
+                             float* dout_or_null, void* stream) {
+    JOVA_CHECK_ARG(outputs && weights && target && loss && n >= 1, "mse_loss: bad argument");
+    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, outputs, weights, target, n, loss,
+                       dout_or_null);
+    JOVA_CHECK_LAUNCH("mse_loss");
+    return JOVA_OK;
+}
+
+extern "C" int jova_sgd_step(float* params, const float* grads, float* momentum_buf_or_null, int64_t n, float lr,
+                             float weight_decay, float momentum, float grad_scale, int first_step, void* stream) {
+    JOVA_CHECK_ARG(params && grads && n >= 0, "sgd_step: bad argument");
+    if (n == 0) return JOVA_OK;
+    hipLaunchKernelGGL(sgd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, params, grads,
+                       momentum_buf_or_null, (long long)n, lr, weight_decay, momentum, grad_scale, first_step);
+    JOVA_CHECK_LAUNCH("sgd_step");
+    return JOVA_OK;
+}
+
+extern "C" int jova_adamax_step(float* params, const float* grads, float* exp_avg, float* exp_inf, int64_t n, float lr,
+                                float beta1, float beta2, float eps, float weight_decay, float grad_scale, int step,
+                                void* stream) {
+    JOVA_CHECK_ARG(params && grads && exp_avg && exp_inf && n >= 0 && step >= 1, "adamax_step: bad argument");
+    if (n == 0) return JOVA_OK;
+    const float bc = 1.f - powf(beta1, (float)step);
+    hipLaunchKernelGGL(adamax_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_inf, (long long)n, lr, beta1, beta2, eps, weight_decay, grad_scale, bc);
+    JOVA_CHECK_LAUNCH("adamax_step");
+    return JOVA_OK;
+}
+
+extern "C" int jova_relu_fwd(const float* x, int64_t n, float* y, void* stream) {
+    JOVA_CHECK_ARG(x && y && n >= 0, "relu_fwd: bad argument");
+    if (n == 0) return JOVA_OK;
+    hipLaunchKernelGGL(relu_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, y);
+    JOVA_CHECK_LAUNCH("relu_fwd");
+    return JOVA_OK;
+}
+
+extern "C" int jova_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* stream) {
+    JOVA_CHECK_ARG(dy && y && dx && n >= 0, "relu_bwd: bad argument");
+    if (n == 0) return JOVA_OK;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, (long long)n, dx);
+    JOVA_CHECK_LAUNCH("relu_bwd");
+    return JOVA_OK;
+}
+
+extern "C" int jova_axpy(const float* x, float a, int64_t n, float* y, void* stream) {
+    JOVA_CHECK_ARG(x && y && n >= 0, "axpy: bad argument");
+    if (n == 0) return JOVA_OK;
+    hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, a, (long long)n, y);
+    JOVA_CHECK_LAUNCH("axpy");
+    return JOVA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ error channel
+#include <stdarg.h>
+static thread_local char g_err[512] = "";
+void jova_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* jova_last_error(void) { return g_err; }
+extern "C" int jova_abi_version(void) { return JOVA_HIP_ABI_VERSION; }

@@ -1,0 +1,606 @@
+"""autograd glue between the reference-shaped nn.Modules and the HIP kernels (C ABI in include/jova_hip.h).
+
+Every Function's forward/backward only (a) allocates outputs with torch (device memory is PyTorch's job here) and
+(b) enqueues kernels of libjova_hip.so on torch's current stream.  No torch math runs on the hot path.
+
+Parameter gradients: the kernels *accumulate*.  If a parameter already has a ``.grad`` (the trainer keeps all of
+them as views of one flat buffer that it zeroes once per step), the kernels add straight into it and the Function
+returns ``None`` for that input; otherwise a zero tensor is allocated, filled and returned to autograd.
+"""
+import ctypes
+import math
+
+import torch
+
+from .. import _lib
+from .._lib import P, call, ptr_array, stream
+
+_F32 = torch.float32
+
+
+def _empty(shape, like, dtype=_F32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _zeros(shape, like, dtype=_F32):
+    return torch.zeros(shape, dtype=dtype, device=like.device)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _GradSink(object):
+    """Where a parameter's gradient is accumulated (see module docstring)."""
+
+    def __init__(self, params):
+        self.targets, self.returns = [], []
+        for p in params:
+            if p is None:
+                self.targets.append(None)
+                self.returns.append(None)
+            elif not p.requires_grad:            # frozen parameter: kernels still need somewhere to write
+                self.targets.append(torch.zeros_like(p))
+                self.returns.append(None)
+            elif p.grad is not None:
+                self.targets.append(p.grad)
+                self.returns.append(None)
+            else:
+                g = torch.zeros_like(p)
+                self.targets.append(g)
+                self.returns.append(g)
+
+
+# ------------------------------------------------------------------------------------------------------ topology
+class Topology(object):
+    """Device-side view of one batch graph: the [1], [3], [4:] entries of the reference's gconv input list
+    (jova/data/data.py:291-296) plus what the kernels derive from them once per batch."""
+
+    def __init__(self, deg_slice, adj_lists, n_atoms_lst, n_atoms):
+        dev = deg_slice.device
+        _lib.require_gpu(deg_slice)
+        self.deg_slice = _c(deg_slice.to(torch.int64))
+        assert self.deg_slice.shape == (11, 2), "deg_slice must be [11, 2] (max_deg 10, min_deg 0)"
+        assert len(adj_lists) == 10, "expected adjacency lists for degrees 1..10"
+        self.adj = []
+        for d, a in enumerate(adj_lists, start=1):
+            _lib.require_gpu(a)
+            a = _c(a.to(torch.int32))
+            assert a.numel() == 0 or (a.dim() == 2 and a.shape[1] == d), "adjacency list %d has shape %s" % (d, a.shape)
+            self.adj.append(a)
+        self.adj_ptrs = ptr_array(self.adj)
+        self.n_atoms = int(n_atoms)
+        self.n_atoms_lst = [int(v) for v in n_atoms_lst] if n_atoms_lst is not None else None
+        self.sym_flag = torch.empty(1, dtype=torch.int32, device=dev)
+        call("jova_adj_symmetry", self.n_atoms, P(self.deg_slice), self.adj_ptrs, P(self.sym_flag), stream())
+        self._mol_off = None
+
+    @property
+    def mol_off(self):
+        if self._mol_off is None:
+            off = [0]
+            for n in self.n_atoms_lst:
+                off.append(off[-1] + n)
+            self._mol_off = torch.tensor(off, dtype=torch.int32).to(self.deg_slice.device, non_blocking=True)
+        return self._mol_off
+
+
+def topology_of(input_data):
+    """Topology of a gconv input list, built once per batch and cached on the deg_slice tensor object."""
+    ds = input_data[1]
+    topo = getattr(ds, "_jova_topology", None)
+    if topo is None:
+        topo = Topology(ds, input_data[4:], input_data[3], input_data[0].shape[0])
+        try:
+            ds._jova_topology = topo
+        except Exception:
+            pass
+    return topo
+
+
+# ------------------------------------------------------------------------------------------------------ graph ops
+class GraphConvFunction(torch.autograd.Function):
+    """GraphConvLayer.forward (jova/nn/layers.py:295-347) as one launch; backward as two."""
+
+    @staticmethod
+    def forward(ctx, atoms, topo, relu, stats, *wb):
+        weights, biases = wb[:21], wb[21:]
+        atoms = _c(atoms)
+        is_i64 = atoms.dtype == torch.int64
+        if not is_i64 and atoms.dtype != _F32:
+            raise RuntimeError("GraphConvLayer: atom features must be int64 or float32, got %s" % atoms.dtype)
+        n, f_in = atoms.shape
+        f_out = weights[0].shape[0]
+        out = _empty((n, f_out), atoms)
+        call("jova_graphconv_fwd", P(atoms), int(is_i64), n, f_in, f_out, P(topo.deg_slice), topo.adj_ptrs,
+             ptr_array(weights), ptr_array(biases), int(relu), P(out), P(stats), stream())
+        ctx.topo, ctx.relu, ctx.is_i64, ctx.params = topo, relu, is_i64, wb
+        ctx.save_for_backward(atoms, out)
+        ctx.weights = weights
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        atoms, out = ctx.saved_tensors
+        topo = ctx.topo
+        dy = _c(dy)
+        n, f_in = atoms.shape
+        f_out = out.shape[1]
+        sink = _GradSink(ctx.params)
+        need_dx = (not ctx.is_i64) and ctx.needs_input_grad[0]
+        dx = _empty((n, f_in), out) if need_dx else None
+        gbuf = _empty((n, f_in), out) if need_dx else None
+        call("jova_graphconv_bwd", P(atoms), int(ctx.is_i64), n, f_in, f_out, P(topo.deg_slice), topo.adj_ptrs,
+             ptr_array(ctx.weights), P(dy), P(out) if ctx.relu else None, ptr_array(sink.targets[:21]),
+             ptr_array(sink.targets[21:]), P(dx), P(gbuf), P(topo.sym_flag), stream())
+        return (dx, None, None, None) + tuple(sink.returns)
+
+
+class GraphPoolFunction(torch.autograd.Function):
+    """GraphPool.forward (jova/nn/layers.py:356-393)."""
+
+    @staticmethod
+    def forward(ctx, atoms, topo):
+        atoms = _c(atoms.float())
+        n, f = atoms.shape
+        out = _empty((n, f), atoms)
+        arg = _empty((n, f), atoms, torch.uint8)
+        call("jova_graphpool_fwd", P(atoms), n, f, P(topo.deg_slice), topo.adj_ptrs, P(out), P(arg), stream())
+        ctx.topo = topo
+        ctx.save_for_backward(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        topo = ctx.topo
+        dy = _c(dy)
+        n, f = dy.shape
+        dx = _empty((n, f), dy)
+        call("jova_graphpool_bwd", P(dy), P(arg), n, f, P(topo.deg_slice), topo.adj_ptrs, P(dx), P(topo.sym_flag), 0,
+             stream())
+        return dx, None
+
+
+class Gather2DFunction(torch.autograd.Function):
+    """GraphGather2D's split / pad / stack (jova/nn/layers.py:429-432)."""
+
+    @staticmethod
+    def forward(ctx, atoms, topo):
+        atoms = _c(atoms)
+        n, g = atoms.shape
+        lst = topo.n_atoms_lst
+        if sum(lst) != n:
+            raise RuntimeError("split_with_sizes expects n_atoms_lst to sum to %d, got %d" % (n, sum(lst)))
+        a_max, bsz = max(lst), len(lst)
+        out = _empty((a_max, bsz, g), atoms)
+        call("jova_gather2d_fwd", P(atoms), P(topo.mol_off), a_max, bsz, g, P(out), stream())
+        ctx.topo, ctx.shape = topo, (n, g, a_max, bsz)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, g, a_max, bsz = ctx.shape
+        dout = _c(dout)
+        dx = _empty((n, g), dout)
+        call("jova_gather2d_bwd", P(dout), P(ctx.topo.mol_off), a_max, bsz, g, P(dx), stream())
+        return dx, None
+
+
+class NonsatFunction(torch.autograd.Function):
+    """nonsat_activation (jova/nn/models.py:458-478): data-dependent trip count decided on the device."""
+
+    last_n_eval = None          # device int32 [3] of the most recent call (evaluations, arrivals, timeout flag)
+
+    @staticmethod
+    def forward(ctx, x, ep, max_iter):
+        x = _c(x)
+        n = x.numel()
+        out = torch.empty_like(x)
+        dfac = torch.empty_like(x)
+        n_eval = _empty((3,), x, torch.int32)
+        ws = _empty((int(_lib.lib().jova_nonsat_workspace_bytes(n)),), x, torch.uint8)
+        call("jova_nonsat_fwd", P(x), n, float(ep), int(max_iter), P(out), P(dfac), P(n_eval), P(ws), stream())
+        NonsatFunction.last_n_eval = n_eval
+        ctx.save_for_backward(dfac)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (dfac,) = ctx.saved_tensors
+        dout = _c(dout)
+        dx = torch.empty_like(dout)
+        call("jova_mul", P(dout), P(dfac), dout.numel(), P(dx), stream())
+        return dx, None, None
+
+
+# ------------------------------------------------------------------------------------------------------ dense helpers
+def _addr(t, offset=0):
+    return ctypes.c_void_p(t.data_ptr() + 4 * offset)
+
+
+def gemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha=1.0, bias=None, residual=None, ldr=0, relu=False, splitk=1,
+         nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0)):
+    """Thin wrapper over jova_gemm_f32; A, B, C, bias, residual are ctypes addresses (see _addr)."""
+    call("jova_gemm_f32", A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, float(alpha), bias, residual, ldr, int(relu),
+         splitk, nb1, nb2, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], stream())
+
+
+def linear_fwd(x2d, w, b, out2d, relu=False, residual=None):
+    """out[M,N] = x[M,K] @ w[N,K]^T + b (+ residual) (ReLU)."""
+    M, K = x2d.shape
+    N = w.shape[0]
+    gemm(_addr(x2d), K, 1, _addr(w), 1, K, _addr(out2d), N, M, N, K, bias=P(b) if b is not None else None,
+         residual=_addr(residual) if residual is not None else None, ldr=N, relu=relu)
+
+
+def linear_bwd_data(dy2d, w, dx2d, residual=None):
+    """dx[M,K] = dy[M,N] @ w[N,K] (+ residual)."""
+    M, N = dy2d.shape
+    K = w.shape[1]
+    gemm(_addr(dy2d), N, 1, _addr(w), K, 1, _addr(dx2d), K, M, K, N,
+         residual=_addr(residual) if residual is not None else None, ldr=K)
+
+
+def _splitk_for(out_rows, out_cols, k):
+    blocks = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+    sk = max(1, min(512 // max(blocks, 1), (k + 255) // 256))
+    return min(sk, 64)
+
+
+def linear_bwd_weight(dy2d, x2d, dw, db):
+    """dw[N,K] += dy[M,N]^T @ x[M,K];  db[N] += column sums of dy."""
+    M, N = dy2d.shape
+    K = x2d.shape[1]
+    if dw is not None:
+        sk = _splitk_for(N, K, M)
+        # split-K adds atomically into dw (accumulate semantics); a single split must accumulate too -> residual = dw
+        if sk > 1:
+            gemm(_addr(dy2d), 1, N, _addr(x2d), K, 1, _addr(dw), K, N, K, M, splitk=sk)
+        else:
+            gemm(_addr(dy2d), 1, N, _addr(x2d), K, 1, _addr(dw), K, N, K, M, residual=_addr(dw), ldr=K)
+    if db is not None:
+        call("jova_colsum_add", P(dy2d), M, N, N, P(db), stream())
+
+
+class LinearFunction(torch.autograd.Function):
+    """nn.Linear (+ optional fused ReLU) over the last dimension."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x = _c(x)
+        k = x.shape[-1]
+        x2d = x.reshape(-1, k)
+        out = _empty(x.shape[:-1] + (weight.shape[0],), x)
+        linear_fwd(x2d, weight, bias, out.view(-1, weight.shape[0]), relu=relu)
+        ctx.relu = relu
+        ctx.params = (weight, bias)
+        ctx.save_for_backward(x2d, out if relu else None)
+        ctx.xshape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, out = ctx.saved_tensors
+        weight, bias = ctx.params
+        dy = _c(dy)
+        n = weight.shape[0]
+        dy2d = dy.reshape(-1, n)
+        if ctx.relu:
+            dz = torch.empty_like(dy2d)
+            call("jova_relu_bwd", P(dy2d), P(out.view(-1, n)), dy2d.numel(), P(dz), stream())
+            dy2d = dz
+        sink = _GradSink((weight, bias))
+        linear_bwd_weight(dy2d, x2d, sink.targets[0], sink.targets[1])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty(x2d.shape, dy)
+            linear_bwd_data(dy2d, weight, dx)
+            dx = dx.view(ctx.xshape)
+        return dx, sink.returns[0], sink.returns[1], None
+
+
+class BatchNormFunction(torch.autograd.Function):
+    """nn.BatchNorm1d in training mode over [rows, C] (+ optional fused ReLU); running stats updated in-kernel."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches, eps, momentum, relu, stats):
+        x = _c(x)
+        n, c = x.shape
+        if n < 2:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
+        if stats is None:
+            stats = _empty((2, c), x, torch.float64)
+            call("jova_colstats", P(x), n, c, P(stats), stream())
+        y = torch.empty_like(x)
+        mean_rstd = _empty((2, c), x)
+        call("jova_batchnorm_fwd", P(x), n, c, P(stats), P(gamma), P(beta), float(eps), float(momentum),
+             P(running_mean), P(running_var), P(num_batches), int(relu), P(y), P(mean_rstd), stream())
+        ctx.relu = relu
+        ctx.params = (gamma, beta)
+        ctx.save_for_backward(x, y if relu else None, mean_rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean_rstd = ctx.saved_tensors
+        gamma, beta = ctx.params
+        dy = _c(dy)
+        n, c = x.shape
+        sink = _GradSink((gamma, beta))
+        dg = sink.targets[0] if sink.targets[0] is not None else _zeros((c,), x)
+        db = sink.targets[1] if sink.targets[1] is not None else _zeros((c,), x)
+        dx = torch.empty_like(x)
+        ws = _empty((2, c), x, torch.float64)
+        call("jova_batchnorm_bwd", P(x), P(dy), P(y) if ctx.relu else None, P(mean_rstd), P(gamma), n, c, P(dx), P(dg),
+             P(db), P(ws), stream())
+        return dx, sink.returns[0], sink.returns[1], None, None, None, None, None, None, None
+
+
+def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps, relu):
+    """Inference-mode BatchNorm1d through the same apply kernel (mean / rstd from the running statistics)."""
+    x = _c(x)
+    n, c = x.shape
+    mean_rstd = torch.stack([running_mean, torch.rsqrt(running_var + eps)]).contiguous()
+    # a zero-variance-free way to reuse jova_batchnorm_fwd would recompute stats; the apply kernel is reached by
+    # feeding statistics that reproduce mean_rstd exactly: sum = n*mean, sumsq = n*(var + mean^2)
+    stats = torch.stack([running_mean.double() * n, (running_var.double() + running_mean.double() ** 2) * n])
+    y = torch.empty_like(x)
+    call("jova_batchnorm_fwd", P(x), n, c, P(stats.contiguous()), P(gamma), P(beta), float(eps), 0.0, None, None, None,
+         int(relu), P(y), P(mean_rstd), stream())
+    return y
+
+
+class ReLUFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        y = torch.empty_like(x)
+        call("jova_relu_fwd", P(x), x.numel(), P(y), stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        call("jova_relu_bwd", P(dy), P(y), dy.numel(), P(dx), stream())
+        return dx
+
+
+class _DropoutState(object):
+    """Philox (seed, offset) bookkeeping: one offset per dropout call, seeded from torch's global seed."""
+    offset = 0
+
+    @classmethod
+    def next(cls):
+        cls.offset += 1
+        return torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, cls.offset
+
+
+def dropout_apply(x2d_addr, rows, n, ld, p, seed, offset, out_addr):
+    call("jova_dropout", x2d_addr, rows, n, ld, float(p), seed, offset, out_addr, stream())
+
+
+class DropoutFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        x = _c(x)
+        y = torch.empty_like(x)
+        ctx.key = _DropoutState.next()
+        ctx.p = p
+        dropout_apply(P(x), 1, x.numel(), x.numel(), p, ctx.key[0], ctx.key[1], P(y))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        dropout_apply(P(dy), 1, dy.numel(), dy.numel(), ctx.p, ctx.key[0], ctx.key[1], P(dx))
+        return dx, None
+
+
+# ------------------------------------------------------------------------------------------------------ protein
+class Prot2VecFunction(torch.autograd.Function):
+    """Embedding gather + reshape + activation + permute of Prot2Vec.forward (jova/nn/models.py:704-715)."""
+
+    @staticmethod
+    def forward(ctx, emb, table, prot_off, prot_len, p_max, window, relu):
+        bsz = prot_off.shape[0]
+        vocab, e = emb.shape[0] - 1, emb.shape[1]
+        out = _empty((p_max, bsz, window * e), emb)
+        call("jova_prot2vec_fwd", P(table), P(prot_off), P(prot_len), P(emb), bsz, p_max, window, e, vocab, int(relu),
+             P(out), None, stream())
+        ctx.args = (table, prot_off, prot_len, p_max, window, relu, bsz, vocab, e)
+        ctx.params = (emb,)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        table, prot_off, prot_len, p_max, window, relu, bsz, vocab, e = ctx.args
+        dout = _c(dout)
+        sink = _GradSink(ctx.params)
+        if sink.targets[0] is not None:
+            call("jova_prot2vec_bwd", P(table), P(prot_off), P(prot_len), P(dout), P(out), bsz, p_max, window, e,
+                 vocab, int(relu), P(sink.targets[0]), stream())
+        return sink.returns[0], None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------ joint attention
+class JointAttentionFunction(torch.autograd.Function):
+    """JointAttention.forward (jova/nn/models.py:939-973) up to and including the view pooling, as one autograd node.
+
+    params per layer i (order): in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias,
+                                linear1.weight, linear1.bias, linear2.weight, linear2.bias, normalize.weight, normalize.bias
+    head of the list: lin_prjs[v].weight, lin_prjs[v].bias for every view, then attn_norm.weight, attn_norm.bias.
+    """
+
+    @staticmethod
+    def forward(ctx, n_views, num_heads, num_layers, dprob, training, *args):
+        views = [_c(v) for v in args[:n_views]]
+        params = args[n_views:]
+        prj = params[:2 * n_views]
+        attn_g, attn_b = params[2 * n_views], params[2 * n_views + 1]
+        layers = [params[2 * n_views + 2 + 10 * i: 2 * n_views + 2 + 10 * (i + 1)] for i in range(num_layers)]
+        bsz = views[0].shape[1]
+        L = prj[0].shape[0]
+        segs = [v.shape[0] for v in views]
+        S = sum(segs)
+        T = S * bsz
+        H = num_heads
+        hd = L // H
+        Sp = (S + 3) // 4 * 4
+        ref = views[0]
+        seg_off = [0]
+        for s in segs:
+            seg_off.append(seg_off[-1] + s)
+        p_drop = float(dprob) if training else 0.0
+
+        x = _empty((T, L), ref)
+        for v in range(n_views):
+            xv = views[v].reshape(-1, views[v].shape[2])
+            linear_fwd(xv, prj[2 * v], prj[2 * v + 1], x[seg_off[v] * bsz: seg_off[v + 1] * bsz])
+        saved = []
+        for lp in layers:
+            w_in, b_in, w_o, b_o, w1, b1, w2, b2, g2, be2 = lp
+            qkv = _empty((T, 3 * L), ref)
+            linear_fwd(x, w_in, b_in, qkv)
+            probs = _empty((bsz * H, S, Sp), ref)
+            # scores[b,h][s][s'] = (q . k) / sqrt(hd)
+            gemm(_addr(qkv), bsz * 3 * L, 1, _addr(qkv, L), 1, bsz * 3 * L, _addr(probs), Sp, S, S, hd,
+                 alpha=1.0 / math.sqrt(hd), nb1=bsz, nb2=H, sA=(3 * L, hd), sB=(3 * L, hd), sC=(H * S * Sp, S * Sp))
+            call("jova_softmax_fwd", P(probs), bsz * H * S, S, Sp, P(probs), stream())
+            key = None
+            pd = probs
+            if p_drop > 0:
+                key = _DropoutState.next()
+                pd = torch.empty_like(probs)
+                dropout_apply(P(probs), bsz * H * S, S, Sp, p_drop, key[0], key[1], P(pd))
+            o = _empty((T, L), ref)
+            # o[s][b][h*hd + d] = sum_s' pd[b,h][s][s'] v[s'][b][h*hd + d]
+            gemm(_addr(pd), Sp, 1, _addr(qkv, 2 * L), bsz * 3 * L, 1, _addr(o), bsz * L, S, hd, S, nb1=bsz, nb2=H,
+                 sA=(H * S * Sp, S * Sp), sB=(3 * L, hd), sC=(L, hd))
+            del pd
+            xp = _empty((T, L), ref)
+            linear_fwd(o, w_o, b_o, xp)
+            x1 = _empty((T, L), ref)
+            mr1 = _empty((T, 2), ref)
+            call("jova_layernorm_fwd", P(x), P(xp), P(attn_g), P(attn_b), T, L, 1e-5, P(x1), P(mr1), stream())
+            hid = _empty((T, w1.shape[0]), ref)
+            linear_fwd(x1, w1, b1, hid, relu=True)
+            f = _empty((T, L), ref)
+            linear_fwd(hid, w2, b2, f)
+            x2 = _empty((T, L), ref)
+            mr2 = _empty((T, 2), ref)
+            call("jova_layernorm_fwd", P(f), P(x1), P(g2), P(be2), T, L, 1e-5, P(x2), P(mr2), stream())
+            saved.append((x, qkv, probs, o, xp, x1, mr1, hid, f, mr2, key))
+            x = x2
+        seg_off_dev = torch.tensor(seg_off, dtype=torch.int32).to(ref.device, non_blocking=True)
+        out = _empty((bsz, n_views * L), ref)
+        call("jova_viewpool_fwd", P(x), P(seg_off_dev), n_views, bsz, L, P(out), stream())
+        ctx.cfg = (n_views, H, num_layers, p_drop, bsz, L, segs, S, Sp, T, hd, seg_off, seg_off_dev)
+        ctx.views, ctx.params, ctx.saved = views, params, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n_views, H, num_layers, p_drop, bsz, L, segs, S, Sp, T, hd, seg_off, seg_off_dev = ctx.cfg
+        views, params, saved = ctx.views, ctx.params, ctx.saved
+        ref = views[0]
+        sink = _GradSink(params)
+        tg = sink.targets
+        prj = params[:2 * n_views]
+        attn_g = params[2 * n_views]
+        dout = _c(dout)
+        dx = _empty((T, L), ref)
+        call("jova_viewpool_bwd", P(dout), P(seg_off_dev), n_views, bsz, L, S, P(dx), stream())
+        scale = 1.0 / math.sqrt(hd)
+        for i in reversed(range(num_layers)):
+            base = 2 * n_views + 2 + 10 * i
+            w_in, b_in, w_o, b_o, w1, b1, w2, b2, g2, be2 = params[base: base + 10]
+            x, qkv, probs, o, xp, x1, mr1, hid, f, mr2, key = saved[i]
+            inner = w1.shape[0]
+            # LN2: z2 = f + x1
+            dz2 = _empty((T, L), ref)
+            call("jova_layernorm_bwd", P(f), P(x1), P(dx), P(g2), P(mr2), T, L, P(dz2), P(tg[base + 8]),
+                 P(tg[base + 9]), stream())
+            # FFN: f = hid @ w2^T + b2 ; hid = relu(x1 @ w1^T + b1)
+            linear_bwd_weight(dz2, hid, tg[base + 6], tg[base + 7])
+            dhid = _empty((T, inner), ref)
+            linear_bwd_data(dz2, w2, dhid)
+            call("jova_relu_bwd", P(dhid), P(hid), dhid.numel(), P(dhid), stream())
+            linear_bwd_weight(dhid, x1, tg[base + 4], tg[base + 5])
+            dx1 = _empty((T, L), ref)
+            linear_bwd_data(dhid, w1, dx1, residual=dz2)          # + residual branch of LN2
+            del dhid
+            # LN1: z1 = x + xp (shared attn_norm)
+            dz1 = _empty((T, L), ref)
+            call("jova_layernorm_bwd", P(x), P(xp), P(dx1), P(attn_g), P(mr1), T, L, P(dz1), P(tg[2 * n_views]),
+                 P(tg[2 * n_views + 1]), stream())
+            # out_proj: xp = o @ w_o^T + b_o
+            linear_bwd_weight(dz1, o, tg[base + 2], tg[base + 3])
+            do = _empty((T, L), ref)
+            linear_bwd_data(dz1, w_o, do)
+            # attention core
+            pd = probs
+            if p_drop > 0:
+                pd = torch.empty_like(probs)
+                dropout_apply(P(probs), bsz * H * S, S, Sp, p_drop, key[0], key[1], P(pd))
+            dqkv = _empty((T, 3 * L), ref)
+            # dv[s'][d] = sum_s pd[s][s'] do[s][d]
+            gemm(_addr(pd), 1, Sp, _addr(do), bsz * L, 1, _addr(dqkv, 2 * L), bsz * 3 * L, S, hd, S, nb1=bsz, nb2=H,
+                 sA=(H * S * Sp, S * Sp), sB=(L, hd), sC=(3 * L, hd))
+            # dp[s][s'] = sum_d do[s][d] v[s'][d]
+            dp = pd if p_drop > 0 else torch.empty_like(probs)
+            gemm(_addr(do), bsz * L, 1, _addr(qkv, 2 * L), 1, bsz * 3 * L, _addr(dp), Sp, S, S, hd, nb1=bsz, nb2=H,
+                 sA=(L, hd), sB=(3 * L, hd), sC=(H * S * Sp, S * Sp))
+            if p_drop > 0:
+                dropout_apply(P(dp), bsz * H * S, S, Sp, p_drop, key[0], key[1], P(dp))
+            call("jova_softmax_bwd", P(probs), P(dp), bsz * H * S, S, Sp, P(dp), stream())
+            # dq[s][d] = scale * sum_s' ds[s][s'] k[s'][d] ;  dk[s'][d] = scale * sum_s ds[s][s'] q[s][d]
+            gemm(_addr(dp), Sp, 1, _addr(qkv, L), bsz * 3 * L, 1, _addr(dqkv), bsz * 3 * L, S, hd, S, alpha=scale,
+                 nb1=bsz, nb2=H, sA=(H * S * Sp, S * Sp), sB=(3 * L, hd), sC=(3 * L, hd))
+            gemm(_addr(dp), 1, Sp, _addr(qkv), bsz * 3 * L, 1, _addr(dqkv, L), bsz * 3 * L, S, hd, S, alpha=scale,
+                 nb1=bsz, nb2=H, sA=(H * S * Sp, S * Sp), sB=(3 * L, hd), sC=(3 * L, hd))
+            del dp, pd
+            linear_bwd_weight(dqkv, x, tg[base], tg[base + 1])
+            dx = _empty((T, L), ref)
+            linear_bwd_data(dqkv, w_in, dx, residual=dz1)         # + residual branch of LN1
+        # view projections
+        grads_in = []
+        for v in range(n_views):
+            dxv = dx[seg_off[v] * bsz: seg_off[v + 1] * bsz]
+            xv = views[v].reshape(-1, views[v].shape[2])
+            linear_bwd_weight(dxv, xv, tg[2 * v], tg[2 * v + 1])
+            if ctx.needs_input_grad[5 + v]:
+                gv = _empty(xv.shape, ref)
+                linear_bwd_data(dxv, prj[2 * v], gv)
+                grads_in.append(gv.view(views[v].shape))
+            else:
+                grads_in.append(None)
+        ctx.saved = None
+        return (None, None, None, None, None) + tuple(grads_in) + tuple(sink.returns)
+
+
+class MSELossFunction(torch.autograd.Function):
+    """nn.MSELoss()(outputs * weights, target) (proj/dti/train_joint_attn.py:464-465)."""
+
+    @staticmethod
+    def forward(ctx, outputs, weights, target):
+        o, w, y = _c(outputs), _c(weights), _c(target)
+        loss = _empty((), o)
+        dout = torch.empty_like(o)
+        call("jova_mse_loss", P(o), P(w), P(y), o.numel(), P(loss), P(dout), stream())
+        ctx.save_for_backward(dout)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dout,) = ctx.saved_tensors
+        scale = dloss.reshape(1).to(dout.dtype).expand(dout.numel()).contiguous()
+        g = torch.empty_like(dout)
+        call("jova_mul", P(dout), P(scale), dout.numel(), P(g), stream())
+        return g, None, None

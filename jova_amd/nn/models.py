@@ -1,0 +1,238 @@
+"""HIP-backed counterparts of the reference's hot-path models, same names / signatures / state-dict keys as
+/root/reference/jova/nn/models.py: GraphConvSequential :331-349, NonsatActivation :448-478, NwayForward :601-611,
+Prot2Vec :685-715 (+ _construct_embedding_indices :214-242), ProteinCNN / ProteinCNN2D :718-771,
+JointAttention :909-973, SegmentWiseLinear :976-1000, SegmentWiseResBlock :1003-1018.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import functional as F_
+from .layers import (BatchNorm1d, Dropout, GraphConvLayer, GraphGather, Linear, ReLU, get_activation_func)
+
+
+class NonsatActivation(nn.Module):
+    def __init__(self, ep=1e-4, max_iter=100):
+        super(NonsatActivation, self).__init__()
+        self.ep = ep
+        self.max_iter = max_iter
+
+    def forward(self, x):
+        return nonsat_activation(x, self.ep, self.max_iter)
+
+
+def nonsat_activation(x, ep=1e-4, max_iter=100):
+    return F_.NonsatFunction.apply(x, ep, max_iter)
+
+
+class GraphConvSequential(nn.Sequential):
+    """Threads ``input[0]`` (atom features) through the modules; the topology entries stay fixed (models.py:336-349).
+
+    Peephole fusions that keep results identical: a GraphConvLayer directly followed by BatchNorm1d hands it the
+    batch statistics computed in the convolution's own epilogue; BatchNorm1d directly followed by ReLU applies it
+    in the same kernel.
+    """
+
+    def forward(self, input):
+        batch_size = input[1]
+        input = list(input[0])
+        mods = list(self._modules.values())
+        pending_stats = None
+        k = 0
+        while k < len(mods):
+            module = mods[k]
+            nxt = mods[k + 1] if k + 1 < len(mods) else None
+            if isinstance(module, BatchNorm1d):
+                fuse = isinstance(nxt, nn.ReLU)
+                module.fused_relu = fuse
+                try:
+                    input[0] = module(input[0], pending_stats if module.training else None)
+                finally:
+                    module.fused_relu = False
+                pending_stats = None
+                if fuse:
+                    k += 1                          # the ReLU ran inside the BatchNorm kernel
+            elif isinstance(module, (nn.BatchNorm1d, nn.Dropout, nn.Linear, nn.ReLU, NonsatActivation)):
+                input[0] = module(input[0])
+            elif isinstance(module, GraphGather):
+                input[0] = module(input, batch_size)
+            elif isinstance(module, GraphConvLayer) and isinstance(nxt, BatchNorm1d) and nxt.training and \
+                    (module.activation is None or isinstance(module.activation, ReLU)):
+                pending_stats = torch.empty((2, module.out_dim), dtype=torch.float64, device=input[0].device)
+                input[0] = module(input, bn_stats=pending_stats)
+            else:
+                input[0] = module(input)
+            k += 1
+        return input[0]
+
+
+class NwayForward(nn.Module):
+    def __init__(self, models):
+        super(NwayForward, self).__init__()
+        self.models = nn.ModuleList(models)
+
+    def forward(self, inputs):
+        return [model(inputs[i]) for i, model in enumerate(self.models)]
+
+
+class ProteinTable(object):
+    """All protein profiles of a ``protein_profile`` dict resident in HBM as one int32 table [rows, window]."""
+
+    def __init__(self, protein_profile, device):
+        self.names = list(protein_profile.keys())
+        self.row_of = {}
+        rows, off = [], 0
+        self.window = None
+        for name in self.names:
+            prof = np.asarray(protein_profile[name])
+            if prof.ndim != 2:
+                raise ValueError("protein profile %r must be [n_segments, window]" % (name,))
+            self.window = prof.shape[1] if self.window is None else self.window
+            self.row_of[name] = (off, prof.shape[0])
+            rows.append(prof.astype(np.int32))
+            off += prof.shape[0]
+        table = np.concatenate(rows, axis=0) if rows else np.zeros((0, 1), np.int32)
+        self.table = torch.from_numpy(np.ascontiguousarray(table)).to(device)
+
+    def batch(self, prot_x, device):
+        """[(source, name), ...] -> (row offsets int32 [B], segment counts int32 [B], P_max)."""
+        meta = np.array([self.row_of[prot[1]] for prot in prot_x], dtype=np.int32)
+        dev = torch.from_numpy(meta).to(device, non_blocking=True)
+        return dev[:, 0].contiguous(), dev[:, 1].contiguous(), int(meta[:, 1].max())
+
+
+def _construct_embedding_indices(prot_x, protein_profile, device, fill_val):
+    """The reference's padded index cube [B, P_max, window] int64 (models.py:214-242), built on the GPU.
+    Not used by Prot2Vec.forward (the kernel derives indices from the resident table); kept for callers/tests."""
+    tab = ProteinTable({p[1]: protein_profile[p[1]] for p in prot_x}, device)
+    off, ln, p_max = tab.batch(prot_x, device)
+    dummy = torch.zeros((fill_val + 1, 1), device=device)
+    out = torch.empty((p_max, len(prot_x), tab.window), device=device)
+    idx = torch.empty((len(prot_x), p_max, tab.window), dtype=torch.int64, device=device)
+    F_.call("jova_prot2vec_fwd", F_.P(tab.table), F_.P(off), F_.P(ln), F_.P(dummy), len(prot_x), p_max, tab.window, 1,
+            fill_val, 0, F_.P(out), F_.P(idx), F_.stream())
+    return idx
+
+
+class Prot2Vec(nn.Module):
+    def __init__(self, protein_profile, vocab_size, embedding_dim, activation='relu', batch_first=False):
+        super(Prot2Vec, self).__init__()
+        self._batch_first = batch_first
+        self.protein_profile = protein_profile
+        self.embedding = nn.Embedding(vocab_size + 1, int(embedding_dim), padding_idx=vocab_size)
+        self.activation = get_activation_func(activation)
+        self._table = None
+
+    def _resident_table(self, device):
+        if self._table is None or self._table.table.device != device:
+            self._table = ProteinTable(self.protein_profile, device)
+        return self._table
+
+    def forward(self, input):
+        w = self.embedding.weight
+        tab = self._resident_table(w.device)
+        off, ln, p_max = input if isinstance(input, tuple) and torch.is_tensor(input[0]) else tab.batch(input, w.device)
+        fused_relu = isinstance(self.activation, ReLU)
+        emb = F_.Prot2VecFunction.apply(w, tab.table, off, ln, p_max, tab.window, fused_relu)
+        if not fused_relu:
+            emb = self.activation(emb)
+        if self._batch_first:
+            emb = emb.permute(1, 0, 2)
+        return emb
+
+
+class ProteinCNN(nn.Module):
+    def __init__(self, dim, window, activation='relu', num_layers=2, pooling_dim=1):
+        super(ProteinCNN, self).__init__()
+        self.activation = get_activation_func(activation)
+        self.pooling_dim = pooling_dim
+        self.lin_kernels = nn.ModuleList([Linear(dim * window, dim * window) for _ in range(num_layers - 1)])
+        self.lin_kernels.append(Linear(dim * window, dim))
+
+    def _convolve(self, prot_x):
+        fused = isinstance(self.activation, ReLU)
+        for kernel in self.lin_kernels:
+            if fused:
+                prot_x = F_.LinearFunction.apply(prot_x, kernel.weight, kernel.bias, True)
+            else:
+                prot_x = self.activation(kernel(prot_x))
+        return prot_x
+
+    def forward(self, prot_x):
+        return torch.mean(self._convolve(prot_x), dim=self.pooling_dim, keepdim=True)
+
+
+class ProteinCNN2D(ProteinCNN):
+    def forward(self, prot_x):
+        return self._convolve(prot_x)
+
+
+class SegmentWiseLinear(nn.Module):
+    def __init__(self, d_model, activation='relu', inner_layer_dim=2048):
+        super(SegmentWiseLinear, self).__init__()
+        self.activation = get_activation_func(activation)
+        self.linear1 = Linear(d_model, inner_layer_dim)
+        self.linear2 = Linear(inner_layer_dim, d_model)
+
+    def forward(self, x):
+        if isinstance(self.activation, ReLU):
+            return self.linear2(F_.LinearFunction.apply(x, self.linear1.weight, self.linear1.bias, True))
+        return self.linear2(self.activation(self.linear1(x)))
+
+
+class SegmentWiseResBlock(nn.Module):
+    def __init__(self, d_model, activation='relu', inner_layer_dim=2048):
+        super(SegmentWiseResBlock, self).__init__()
+        self.normalize = nn.LayerNorm(d_model)
+        self.seg_lin = SegmentWiseLinear(d_model, activation, inner_layer_dim)
+
+    def forward(self, x):
+        # stand-alone use only: inside JointAttention the whole block runs in JointAttentionFunction
+        return self.normalize(x + self.seg_lin(x))
+
+
+class JointAttention(nn.Module):
+    """Joint-view attention fusion (models.py:909-973).  The per-view projections, the MultiheadAttention /
+    LayerNorm / FFN layers and the view pooling run as ONE autograd node over the HIP kernels; the stock torch
+    modules below are parameter containers only (same names, shapes and initialisation as the reference)."""
+
+    def __init__(self, d_dims, latent_dim=256, num_heads=1, num_layers=1, dprob=0., activation='relu',
+                 inner_layer_dim=2048, attn_hook=None):
+        super(JointAttention, self).__init__()
+        if attn_hook:
+            assert callable(attn_hook), "Attention hook must be a function"
+            raise NotImplementedError("attention hooks (explain mode) are outside the training hot path")
+        if activation != 'relu':
+            raise NotImplementedError("the fused joint-attention path implements the reference's default 'relu'")
+        self.attn_hook = attn_hook
+        self.latent_dim = latent_dim
+        self.num_heads = num_heads
+        self.dprob = dprob
+        self.lin_prjs = nn.ModuleList([nn.Linear(in_dim, latent_dim) for in_dim in d_dims])
+        self.attention_models = nn.ModuleList([nn.MultiheadAttention(embed_dim=latent_dim, num_heads=num_heads,
+                                                                     dropout=dprob) for _ in range(num_layers)])
+        self.res_blks = nn.ModuleList([SegmentWiseResBlock(d_model=latent_dim, activation=activation,
+                                                           inner_layer_dim=inner_layer_dim) for _ in range(num_layers)])
+        self.activation = get_activation_func(activation)
+        self.dropout = Dropout(dprob)
+        self.batch_norm = BatchNorm1d(latent_dim * len(d_dims))
+        self.attn_norm = nn.LayerNorm(latent_dim)
+
+    def forward(self, inputs):
+        params = []
+        for lin in self.lin_prjs:
+            params += [lin.weight, lin.bias]
+        params += [self.attn_norm.weight, self.attn_norm.bias]
+        for attn, res in zip(self.attention_models, self.res_blks):
+            params += [attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias,
+                       res.seg_lin.linear1.weight, res.seg_lin.linear1.bias,
+                       res.seg_lin.linear2.weight, res.seg_lin.linear2.bias,
+                       res.normalize.weight, res.normalize.bias]
+        x = F_.JointAttentionFunction.apply(len(inputs), self.num_heads, len(self.attention_models), self.dprob,
+                                            self.training, *(list(inputs) + params))
+        self.batch_norm.fused_relu = True
+        try:
+            x = self.batch_norm(x)
+        finally:
+            self.batch_norm.fused_relu = False
+        return self.dropout(x)

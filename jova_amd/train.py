@@ -1,0 +1,155 @@
+"""Model assembly and training step of the multi-view DTI model, MI355X side.
+
+Counterpart of the reference's harness /root/reference/proj/dti/train_joint_attn.py for the view combination
+``ecfp8-gconv__pcnn2d`` (plus ``psc``): create_ecfp_net :65-67, create_prot_net :70-116, create_gconv_net :155-174,
+create_integrated_net :188-243 (same nn.Sequential structure => same state-dict keys, so reference ``.mod``
+checkpoints load unchanged) and the loop body of Jova.train :428-486 (zero_grad -> forward -> MSELoss(out*w, y)
+-> backward -> optimizer.step).
+
+Differences that are deliberate (MI355X-first):
+  * all parameters live in ONE flat fp32 buffer and all gradients in another; the weight-gradient kernels
+    accumulate straight into it, data parallelism all-reduces that single buffer (RCCL), and the optimizer is one
+    kernel over the flat buffers;
+  * batches are collated to device-resident index tensors (jova_amd/data/collate.py) instead of per-step Python.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .nn import functional as F_
+from .nn.layers import BatchNorm1d, Dropout, GraphConvLayer, GraphGather2D, GraphPool, Linear, ReLU, Unsqueeze
+from .nn.models import GraphConvSequential, JointAttention, NwayForward, Prot2Vec, ProteinCNN2D
+
+TUNED_DAVIS_HPARAMS = {
+    # first row of proj/dti/soek_res/bayopt_search_integrated_view_attn_no_gan_pcnn2d_ecfp8_gconv_dti_2019_11_27__21_57_05_gp.csv
+    "attn_heads": 2, "attn_layers": 1, "lin_dims": [267, 637], "output_dim": 1, "latent_dim": 512, "dprob": 0.211,
+    "tr_batch_size": 128, "optimizer": "sgd", "optimizer__global__lr": 4.70e-3,
+    "optimizer__global__weight_decay": 1.91e-2, "explain_mode": False,
+    "prot": {"model_types": ["pcnn2d"], "vocab_size": 9048, "window": 11, "pcnn_num_layers": 3, "embedding_dim": 22,
+             "psc_dim": 8421},
+    "gconv": {"dim": 194}, "ecfp8": {"dim": 1024},
+}
+
+
+def create_ecfp_net(hparams):
+    return nn.Sequential(Unsqueeze(dim=0))
+
+
+def create_gconv_net(hparams):
+    dim = hparams["gconv"]["dim"]
+    gconv_model = GraphConvSequential(GraphConvLayer(in_dim=75, out_dim=64), BatchNorm1d(64), ReLU(), GraphPool(),
+                                      GraphConvLayer(in_dim=64, out_dim=64), BatchNorm1d(64), ReLU(), GraphPool(),
+                                      Linear(in_features=64, out_features=dim), BatchNorm1d(dim), ReLU(),
+                                      Dropout(hparams["dprob"]), GraphGather2D(activation='nonsat'))
+    return nn.Sequential(gconv_model)
+
+
+def create_prot_net(hparams, model_type, protein_profile):
+    if model_type == "pcnn2d":
+        return nn.Sequential(Prot2Vec(protein_profile=protein_profile, vocab_size=hparams["prot"]["vocab_size"],
+                                      embedding_dim=hparams["prot"]["embedding_dim"], batch_first=False),
+                             ProteinCNN2D(dim=hparams["prot"]["embedding_dim"], window=hparams["prot"]["window"],
+                                          num_layers=hparams["prot"]["pcnn_num_layers"]))
+    if model_type == "p2v":
+        return Prot2Vec(protein_profile=protein_profile, vocab_size=hparams["prot"]["vocab_size"],
+                        embedding_dim=hparams["prot"]["embedding_dim"], batch_first=False)
+    if model_type == "psc":
+        return nn.Sequential(Unsqueeze(dim=0))
+    raise NotImplementedError("protein view %r is outside the hot path (SURVEY.md section 8)" % model_type)
+
+
+def create_integrated_net(hparams, protein_profile, c_views=("ecfp8", "gconv")):
+    """Same module tree as the reference builder: 0 = NwayForward, 1 = JointAttention, then the FC head."""
+    creators = {"ecfp8": create_ecfp_net, "gconv": create_gconv_net}
+    views, seg_dims = [], []
+    for cview in c_views:
+        views.append(creators[cview](hparams))
+        seg_dims.append(hparams[cview]["dim"])
+    for m_type in hparams["prot"]["model_types"]:
+        views.append(create_prot_net(hparams, m_type, protein_profile))
+        if m_type == "psc":
+            seg_dims.append(hparams["prot"]["psc_dim"])
+        elif m_type == "p2v":
+            seg_dims.append(hparams["prot"]["embedding_dim"] * hparams["prot"]["window"])
+        else:
+            seg_dims.append(hparams["prot"]["embedding_dim"])
+    layers = [NwayForward(models=views),
+              JointAttention(d_dims=seg_dims, latent_dim=hparams["latent_dim"], num_heads=hparams["attn_heads"],
+                             num_layers=hparams["attn_layers"], dprob=hparams["dprob"])]
+    p = len(views) * hparams["latent_dim"]
+    for dim in hparams["lin_dims"]:
+        layers += [Linear(p, dim), BatchNorm1d(dim), ReLU(), Dropout(hparams["dprob"])]
+        p = dim
+    layers.append(Linear(in_features=p, out_features=hparams["output_dim"]))
+    return nn.Sequential(*layers)
+
+
+def count_parameters(model):
+    return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
+class FlatParameters(object):
+    """Re-homes every parameter of ``model`` into one flat fp32 buffer (and every gradient into another)."""
+
+    def __init__(self, model):
+        params = [p for p in model.parameters() if p.requires_grad]
+        assert all(p.dtype == torch.float32 for p in params)
+        n = sum(p.numel() for p in params)
+        dev = params[0].device
+        # 64-element alignment keeps every parameter 256-byte aligned for vector loads
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        self.data = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, o in zip(params, offs):
+            self.data[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.data[o:o + p.numel()].view(p.shape)
+            p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        self.params, self.n_params, self.numel = params, n, total
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+class Trainer(object):
+    """One training step = the body of the reference's batch loop (train_joint_attn.py:428-486), no host sync."""
+
+    def __init__(self, model, hparams, world_size=1, process_group=None):
+        self.model = model
+        self.hp = hparams
+        self.flat = FlatParameters(model)
+        self.world_size = world_size
+        self.pg = process_group
+        self.opt = hparams.get("optimizer", "sgd").lower()
+        self.lr = float(hparams.get("optimizer__global__lr", 1e-3))
+        self.wd = float(hparams.get("optimizer__global__weight_decay", 0.0))
+        self.step_idx = 0
+        if self.opt == "adamax":
+            self.exp_avg = torch.zeros_like(self.flat.data)
+            self.exp_inf = torch.zeros_like(self.flat.data)
+        elif self.opt != "sgd":
+            raise NotImplementedError("optimizer %r: the HIP path implements sgd and adamax" % self.opt)
+
+    def forward_loss(self, batch):
+        outputs = self.model(batch.model_input())
+        return F_.MSELossFunction.apply(outputs, batch.w, batch.y), outputs
+
+    def step(self, batch):
+        self.flat.zero_grad()
+        loss, outputs = self.forward_loss(batch)
+        loss.backward()
+        scale = 1.0
+        if self.world_size > 1:
+            torch.distributed.all_reduce(self.flat.grad, group=self.pg)       # RCCL sum over ranks; mean via scale
+            scale = 1.0 / self.world_size
+        self.step_idx += 1
+        f = self.flat
+        if self.opt == "sgd":
+            _lib.call("jova_sgd_step", _lib.P(f.data), _lib.P(f.grad), None, f.numel, self.lr, self.wd, 0.0, scale, 1,
+                      _lib.stream())
+        else:
+            _lib.call("jova_adamax_step", _lib.P(f.data), _lib.P(f.grad), _lib.P(self.exp_avg), _lib.P(self.exp_inf),
+                      f.numel, self.lr, 0.9, 0.999, 1e-8, self.wd, scale, self.step_idx, _lib.stream())
+        return loss, outputs

@@ -1,0 +1,307 @@
+"""GPU parity tests: the HIP path (through the C ABI) against golden vectors exported from the reference and against
+the oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): index tensors bit-exact; fp32 forward/backward within 1e-5 relative.  "Relative" is
+read against the scale of each tensor (max |ref|); gradient tensors that are analytically ~0 are judged on 5 % of the
+largest gradient tensor (helpers.rel_err).  Where the reference's own fp32 result sits further than 1e-5 from the
+fp64 oracle (long reductions, the tiny ill-conditioned e2e fixture), the bound is stated next to the assertion.
+"""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _glist_dev(mols, device, atoms=None):
+    gl = H.oracle_glist(mols, atoms)
+    return [t.to(device) if torch.is_tensor(t) else t for t in gl]
+
+
+def _load_sd(module, z, prefix):
+    sd = H.sd(z, prefix)
+    module.load_state_dict(sd)
+    return module
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("layout", ["kc_kc", "kc_rc", "rc_kc", "rc_rc"])
+@pytest.mark.parametrize("shape", [(5, 7, 3), (128, 128, 16), (130, 67, 75), (300, 194, 64), (257, 512, 242), (64, 1, 637)])
+def test_gemm_layouts(device, layout, shape):
+    from jova_amd.nn import functional as F_
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M * 1000 + N + K)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    want = torch.relu((a.double() @ b.double()) * 0.5 + bias.double() + res.double()).float()
+    a_kc, b_kc = layout.split("_")
+    A = (a if a_kc == "kc" else a.t().contiguous()).to(device)         # [M,K] or [K,M]
+    B = (b.t().contiguous() if b_kc == "kc" else b).to(device)         # [N,K] or [K,N]
+    sam, sak = (K, 1) if a_kc == "kc" else (1, M)
+    sbk, sbn = (1, K) if b_kc == "kc" else (N, 1)
+    C = torch.full((M, N), float("nan"), device=device)
+    F_.gemm(F_._addr(A), sam, sak, F_._addr(B), sbk, sbn, F_._addr(C), N, M, N, K, alpha=0.5, bias=F_.P(bias.to(device)),
+            residual=F_._addr(res.to(device)), ldr=N, relu=True)
+    H.assert_close(C, want, tol=2e-6, what="gemm " + layout)
+
+
+def test_gemm_batched_strided_and_splitk(device):
+    from jova_amd.nn import functional as F_
+    g = torch.Generator().manual_seed(5)
+    nb1, nb2, M, N, K = 3, 2, 70, 50, 40
+    a = torch.randn(nb1, nb2, M, K, generator=g)
+    b = torch.randn(nb1, nb2, N, K, generator=g)
+    want = torch.einsum("xymk,xynk->xymn", a.double(), b.double()).float()
+    A, B = a.to(device), b.to(device)
+    C = torch.zeros(nb1, nb2, M, N, device=device)
+    F_.gemm(F_._addr(A), K, 1, F_._addr(B), 1, K, F_._addr(C), N, M, N, K, nb1=nb1, nb2=nb2,
+            sA=(nb2 * M * K, M * K), sB=(nb2 * N * K, N * K), sC=(nb2 * M * N, M * N))
+    H.assert_close(C, want, tol=2e-6, what="batched")
+    # split-K accumulates into C: start from ones
+    M, N, K = 40, 30, 5000
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g)
+    C = torch.ones(M, N, device=device)
+    F_.gemm(F_._addr(a.to(device)), K, 1, F_._addr(b.to(device)), 1, K, F_._addr(C), N, M, N, K, splitk=7)
+    H.assert_close(C, (a.double() @ b.double().t() + 1).float(), tol=2e-6, what="splitk")
+
+
+# ------------------------------------------------------------------------------------------------ graph stack
+@pytest.mark.parametrize("tag", ["l1", "l2", "lin"])
+def test_graphconv_vs_reference_golden(device, tag):
+    from jova_amd.nn.layers import GraphConvLayer
+    z = H.load("op_graphconv")
+    mols = H.unpack_mols(z)
+    layer = _load_sd(GraphConvLayer(75 if tag == "l1" else 64, 64, activation=None if tag == "lin" else "relu"), z,
+                     tag + ".sd.").to(device)
+    x = None
+    if tag != "l1":
+        x = torch.from_numpy(z[tag + ".x"]).to(device).requires_grad_(True)
+    gl = _glist_dev(mols, device, x)
+    stats = torch.empty(2, 64, dtype=torch.float64, device=device)
+    out = layer(gl, bn_stats=stats)
+    H.assert_close(out, z[tag + ".out"], tol=1e-5, what="out")
+    ref = torch.from_numpy(z[tag + ".out"]).double()
+    H.assert_close(stats[0], ref.sum(0).numpy(), tol=1e-5, what="fused BN column sums")
+    H.assert_close(stats[1], (ref * ref).sum(0).numpy(), tol=1e-5, what="fused BN column sums of squares")
+    (out * torch.from_numpy(z[tag + ".gout"]).to(device)).sum().backward()
+    for k in range(21):
+        H.assert_close(layer.linear_layers[k].weight.grad, z["%s.grad.linear_layers.%d.weight" % (tag, k)], tol=1e-5,
+                       what="dW%d" % k)
+        H.assert_close(layer.linear_layers[k].bias.grad, z["%s.grad.linear_layers.%d.bias" % (tag, k)], tol=1e-5,
+                       what="db%d" % k)
+    if x is not None:
+        H.assert_close(x.grad, z[tag + ".gx"], tol=1e-5, what="dx")
+
+
+def test_graphconv_backward_atomic_path_for_asymmetric_adjacency(device):
+    """A directed edge list (not a bond graph) must take the scatter path and still match the oracle."""
+    from jova_amd.nn.layers import GraphConvLayer, GraphPool
+    from oracle import nn_ref as R
+    torch.manual_seed(3)
+    n = 40
+    deg_slice = torch.tensor([[0, 4]] + [[4, 12], [16, 12], [28, 12]] + [[40, 0]] * 7)
+    adj = [torch.randint(0, n, (12, d), dtype=torch.int32) for d in (1, 2, 3)] + \
+          [torch.zeros((0, d), dtype=torch.int32) for d in range(4, 11)]
+    x = torch.randn(n, 64)
+    layer = GraphConvLayer(64, 64)
+    w = [l.weight.detach().double().requires_grad_(True) for l in layer.linear_layers]
+    b = [l.bias.detach().double().requires_grad_(True) for l in layer.linear_layers]
+    xo = x.double().requires_grad_(True)
+    pooled = R.graph_pool(R.graph_conv(xo, deg_slice, adj, w, b), deg_slice, adj)
+    gout = torch.randn(n, 64)
+    (pooled * gout.double()).sum().backward()
+    layer = layer.to(device)
+    xd = x.to(device).requires_grad_(True)
+    gl = [xd, deg_slice.to(device), None, [n]] + [a.to(device) for a in adj]
+    out = GraphPool()([layer(gl)] + gl[1:])
+    assert int(gl[1]._jova_topology.sym_flag.item()) == 0
+    (out * gout.to(device)).sum().backward()
+    H.assert_close(out, pooled.detach().float(), tol=1e-5, what="out")
+    H.assert_close(xd.grad, xo.grad.float(), tol=1e-5, what="dx (atomic scatter)")
+    H.assert_close(layer.linear_layers[2].weight.grad, w[2].grad.float(), tol=1e-5, what="dW")
+
+
+def test_graphpool_ties_vs_reference_golden(device):
+    from jova_amd.nn.layers import GraphPool
+    z = H.load("op_graphpool")
+    x = torch.from_numpy(z["x"]).to(device).requires_grad_(True)
+    gl = _glist_dev(H.unpack_mols(z), device, x)
+    out = GraphPool()(gl)
+    assert int(gl[1]._jova_topology.sym_flag.item()) == 1
+    assert np.array_equal(out.detach().cpu().numpy(), z["out"])                 # max is exact
+    (out * torch.from_numpy(z["gout"]).to(device)).sum().backward()
+    H.assert_close(x.grad, z["gx"], tol=1e-6, what="dx (tie routing: first maximal index, self first)")
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_gather2d_nonsat_vs_reference_golden(device, tag):
+    from jova_amd.nn.layers import GraphGather2D
+    from jova_amd.nn import functional as F_
+    from oracle import nn_ref as R
+    z = H.load("op_gather2d_nonsat")
+    n_atoms = [int(v) for v in z[tag + ".n_atoms"]]
+    x = torch.from_numpy(z[tag + ".x"]).to(device).requires_grad_(True)
+    out = GraphGather2D(activation="nonsat")([x, None, None, n_atoms], len(n_atoms))
+    _, n_eval = R.nonsat(R.gather2d(torch.from_numpy(z[tag + ".x"]), n_atoms))
+    ctrl = F_.NonsatFunction.last_n_eval.cpu().tolist()
+    assert ctrl[0] == n_eval and ctrl[2] == 0, "evaluations %s (oracle %d)" % (ctrl, n_eval)
+    H.assert_close(out, z[tag + ".out"], tol=1e-5, what="out")
+    (out * torch.from_numpy(z[tag + ".gout"]).to(device)).sum().backward()
+    H.assert_close(x.grad, z[tag + ".gx"], tol=1e-5, what="dx")
+    tanh = GraphGather2D()([x.detach(), None, None, n_atoms], len(n_atoms))
+    H.assert_close(tanh, z[tag + ".out_tanh"], tol=1e-6, what="tanh flavour (padding layout)")
+
+
+def test_nonsat_iteration_cap(device):
+    """max_iter is honoured: with ep = 0 the loop runs until the evaluation index exceeds max_iter (max_iter + 2 evaluations)."""
+    from jova_amd.nn import functional as F_
+    from oracle import nn_ref as R
+    x = torch.randn(3000) * 3
+    want, n_eval = R.nonsat(x, ep=-1.0, max_iter=5)
+    out = F_.NonsatFunction.apply(x.to(device), -1.0, 5)
+    assert F_.NonsatFunction.last_n_eval.cpu().tolist()[0] == n_eval == 7
+    H.assert_close(out, want, tol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ protein branch
+def test_prot2vec_vs_reference_golden(device):
+    from jova_amd.nn.models import Prot2Vec, _construct_embedding_indices
+    z = H.load("op_prot2vec")
+    prof = H.profile(z)
+    batch = [("davis", "P%03d" % i) for i in z["batch_prot"]]
+    idx = _construct_embedding_indices(batch, prof, device, 60)
+    assert idx.dtype == torch.int64 and np.array_equal(idx.cpu().numpy(), z["idx"])      # index cube bit-exact
+    p2v = _load_sd(Prot2Vec(prof, 60, 6), z, "sd.").to(device)
+    out = p2v(batch)
+    assert np.array_equal(out.detach().cpu().numpy(), z["out"])
+    (out * torch.from_numpy(z["gout"]).to(device)).sum().backward()
+    H.assert_close(p2v.embedding.weight.grad, z["grad.embedding.weight"], tol=1e-6, what="dE")
+    assert float(p2v.embedding.weight.grad[60].abs().max()) == 0.0
+
+
+def test_pcnn2d_vs_reference_golden(device):
+    from jova_amd.nn.models import ProteinCNN2D
+    z = H.load("op_pcnn2d")
+    net = _load_sd(ProteinCNN2D(dim=6, window=11, num_layers=3), z, "sd.").to(device)
+    x = torch.from_numpy(z["x"]).to(device).requires_grad_(True)
+    out = net(x)
+    H.assert_close(out, z["out"], tol=1e-5, what="out")
+    (out * torch.from_numpy(z["gout"]).to(device)).sum().backward()
+    H.assert_close(x.grad, z["gx"], tol=1e-5, what="dx")
+    for i in range(3):
+        H.assert_close(net.lin_kernels[i].weight.grad, z["grad.lin_kernels.%d.weight" % i], tol=1e-5, what="dW")
+        H.assert_close(net.lin_kernels[i].bias.grad, z["grad.lin_kernels.%d.bias" % i], tol=1e-5, what="db")
+
+
+# ------------------------------------------------------------------------------------------------ joint attention
+def test_joint_attention_vs_reference_golden(device):
+    from jova_amd.nn.models import JointAttention
+    z = H.load("op_joint_attention")
+    ja = _load_sd(JointAttention(d_dims=[40, 12, 6], latent_dim=32, num_heads=2, num_layers=1, dprob=0.,
+                                 inner_layer_dim=48), z, "sd.").to(device)
+    ja.train()
+    xs = [torch.from_numpy(z["x%d" % i]).to(device).requires_grad_(True) for i in range(3)]
+    out = ja(xs)
+    H.assert_close(out, z["out"], tol=1e-5, what="out")
+    (out * torch.from_numpy(z["gout"]).to(device)).sum().backward()
+    for i in range(3):
+        H.assert_close(xs[i].grad, z["gx%d" % i], tol=2e-5, what="dx%d" % i)
+    floor = H.grad_floor(z, "grad.")
+    named = dict(ja.named_parameters())
+    for k in z.files:
+        if k.startswith("grad."):
+            # 2e-5: the reference's own fp32 gradients sit up to 2e-5 from the fp64 oracle here (test_oracle_golden)
+            H.assert_close(named[k[5:]].grad, z[k], tol=2e-5, what=k, floor=floor)
+
+
+def test_attention_dropout_is_consistent_between_forward_and_backward(device):
+    """With dprob > 0 the mask is regenerated in backward from (seed, offset): a finite-difference check along one
+    direction must agree with the analytic gradient when the same mask is replayed."""
+    from jova_amd.nn import functional as F_
+    torch.manual_seed(11)
+    x = torch.randn(4, 1000, device=device)
+    F_._DropoutState.offset = 100
+    y1 = F_.DropoutFunction.apply(x, 0.3)
+    F_._DropoutState.offset = 100
+    y2 = F_.DropoutFunction.apply(x, 0.3)
+    assert torch.equal(y1, y2)
+    keep = (y1 != 0).float().mean().item()
+    assert abs(keep - 0.7) < 0.03
+    H.assert_close(y1[y1 != 0], (x / 0.7)[y1 != 0], tol=1e-6)
+    xg = x.clone().requires_grad_(True)
+    F_._DropoutState.offset = 100
+    F_.DropoutFunction.apply(xg, 0.3).sum().backward()
+    H.assert_close(xg.grad, (y1 != 0).float() / 0.7, tol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ end to end
+def _e2e_setup(device):
+    from jova_amd.data.collate import DtiBatch, process_gconv_view_data
+    from jova_amd.feat.mol_graphs import ConvMol
+    from jova_amd.train import create_integrated_net
+    z = H.load("e2e_small")
+    hp = H.hp(z)
+    hparams = {"attn_heads": hp["heads"], "attn_layers": hp["attn_layers"], "lin_dims": hp["lin_dims"], "output_dim": 1,
+               "latent_dim": hp["latent"], "dprob": hp["dprob"], "optimizer": "sgd",
+               "optimizer__global__lr": hp["lr"], "optimizer__global__weight_decay": hp["wd"],
+               "prot": {"model_types": ["pcnn2d"], "vocab_size": hp["vocab"], "window": hp["window"],
+                        "pcnn_num_layers": hp["pcnn_layers"], "embedding_dim": hp["emb"]},
+               "gconv": {"dim": hp["gconv_dim"]}, "ecfp8": {"dim": hp["ecfp_dim"]}}
+    prof = H.profile(z)
+    net = create_integrated_net(hparams, prof)
+    net.load_state_dict(H.sd(z, "sd0."))
+    net = net.to(device).train()
+    mols = [ConvMol(f, a, smiles=str(i)) for i, (f, a) in enumerate(H.unpack_mols(z))]
+    glist = process_gconv_view_data(mols, device)
+    names = sorted(prof)
+    batch = DtiBatch(torch.from_numpy(z["ecfp"]).to(device), glist, [("davis", names[i]) for i in z["prot_ids"]],
+                     torch.from_numpy(z["y"]).float().to(device), torch.from_numpy(z["w"]).float().to(device))
+    return z, hp, hparams, net, batch
+
+
+def test_e2e_training_step_vs_reference_golden(device):
+    from jova_amd.train import Trainer
+    z, hp, hparams, net, batch = _e2e_setup(device)
+    # the collated index tensors are the reference's, bit for bit
+    ref_gl = H.oracle_glist(H.unpack_mols(z))
+    for got, want in zip(batch.glist, ref_gl):
+        if torch.is_tensor(want):
+            assert got.dtype == want.dtype and torch.equal(got.cpu(), want)
+        else:
+            assert list(got) == list(want)
+    tr = Trainer(net, hparams)
+    tr.flat.zero_grad()
+    loss, out = tr.forward_loss(batch)
+    loss.backward()
+    H.assert_close(out, z["step0.out"], tol=2e-5, what="outputs")
+    assert abs(loss.item() - float(z["step0.loss"])) <= 1e-5 * abs(float(z["step0.loss"]))
+    floor = H.grad_floor(z, "step0.grad.")
+    named = dict(net.named_parameters())
+    for k in z.files:
+        if k.startswith("step0.grad."):
+            # 5e-4: the tiny fixture model (batch 8, BN/LN chains) is ill-conditioned; the reference's own fp32
+            # gradients sit up to 1.3e-4 from the fp64 oracle on these tensors (tests/test_oracle_golden.py)
+            H.assert_close(named[k[len("step0.grad."):]].grad, z[k], tol=5e-4, what=k, floor=floor)
+    # optimizer step + second step: loss of step 1 pins the SGD update and the BatchNorm running statistics
+    net.load_state_dict(H.sd(z, "sd0."))
+    tr.step(batch)
+    sd = net.state_dict()
+    for k in z.files:
+        if k.startswith("step0.sd."):
+            name = k[len("step0.sd."):]
+            if name.endswith("num_batches_tracked"):
+                assert int(sd[name]) == int(z[k])
+            elif "running" in name:
+                H.assert_close(sd[name], z[k], tol=1e-5, what=name)
+            else:
+                gmax = max(float(np.abs(z["step0.grad." + name]).max()), floor)
+                bound = 1e-6 * float(np.abs(z[k]).max()) + hp["lr"] * 5e-4 * gmax
+                assert float(np.abs(sd[name].cpu().numpy() - z[k]).max()) <= bound, name
+    loss1, out1 = tr.step(batch)
+    assert abs(loss1.item() - float(z["step1.loss"])) <= 2e-5 * abs(float(z["step1.loss"]))
+    H.assert_close(out1, z["step1.out"], tol=5e-5, what="outputs after one SGD step")

@@ -1,0 +1,116 @@
+"""CPU tests of the product's host side: batch-graph builder vs golden vectors and vs the oracle, the C-ABI library
+(loads, exports every symbol the header declares, signatures agree with the binding), module/state-dict surface."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from jova_amd import synth
+from jova_amd.feat.mol_graphs import ConvMol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", ["toy4", "deg0_b16", "hubs_b8", "pair_b2", "davis_b128"])
+def test_agglomerate_bit_exact_vs_reference_golden(name):
+    z = H.load("index_" + name)
+    mols = [ConvMol(f, a, smiles="m%d" % i) for i, (f, a) in enumerate(H.unpack_mols(z))]
+    mm = ConvMol.agglomerate_mols(mols)
+    assert mm.nodes.dtype == np.int64 and np.array_equal(mm.nodes, z["nodes"].astype(np.int64))
+    assert mm.deg_slice.dtype == np.int64 and np.array_equal(mm.deg_slice, z["deg_slice"])
+    assert np.array_equal(np.asarray(mm.membership), z["membership"])
+    for d in range(11):
+        got = mm.get_deg_adjacency_lists()[d]
+        assert got.dtype == np.int32 and got.shape == z["adj_%d" % d].shape
+        assert np.array_equal(got, z["adj_%d" % d])
+
+
+@pytest.mark.parametrize("seed,shape,count", [(1, "davis", 64), (8, "graph4k", 48), (64, "kiba", 100)])
+def test_agglomerate_matches_oracle_on_fresh_seeds(seed, shape, count):
+    """Bigger seeded batches than the committed goldens: product builder vs the loop-faithful oracle."""
+    from oracle import mol_graphs as og
+    r = np.random.RandomState(seed)
+    spec = synth.SHAPES[shape]
+    raw = [synth.make_molecule(r, n, spec["deg_cap"], spec["hub_frac"]) for n in spec["atoms"](r, count)]
+    if shape == "davis":
+        raw += [synth.make_molecule(r, 1), synth.make_molecule(r, 2)]      # degree-0 atom, 2-atom molecule
+    want = og.agglomerate([og.SortedMol(f, a) for f, a in raw])
+    cms = [ConvMol(f, a, smiles=str(i)) for i, (f, a) in enumerate(raw)]
+    mm = ConvMol.agglomerate_mols(cms)
+    assert np.array_equal(mm.nodes, want["nodes"])
+    assert np.array_equal(mm.deg_slice, want["deg_slice"])
+    assert np.array_equal(np.asarray(mm.membership), want["membership"])
+    for d in range(11):
+        assert np.array_equal(mm.deg_adj_lists[d], want["deg_adj_lists"][d])
+    # per-molecule surface used by the reference's collators
+    for cm, (f, a) in zip(cms[:8], raw[:8]):
+        sm = og.SortedMol(f, a)
+        assert np.array_equal(cm.get_atom_features(), sm.atom_features)
+        assert cm.get_adjacency_list() == sm.canon_adj
+        assert np.array_equal(cm.deg_slice, sm.deg_slice)
+        for d in range(11):
+            assert np.array_equal(cm.deg_adj_lists[d], sm.deg_adj_lists[d])
+
+
+def test_degree_overflow_raises():
+    f = np.zeros((13, 75), dtype=np.int64)
+    adj = [list(range(1, 13))] + [[0]] * 12          # centre atom with 12 neighbours > max_deg
+    with pytest.raises(IndexError):
+        ConvMol(f, adj)
+
+
+def _header_decls():
+    text = open(os.path.join(ROOT, "include", "jova_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(jova_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        args = m.group(3).strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        decls[m.group(2)] = n
+    return decls
+
+
+def test_abi_library_exports_every_declared_symbol():
+    from jova_amd import _lib
+    decls = _header_decls()
+    assert len(decls) >= 30
+    L = _lib.lib()
+    for name in decls:
+        assert hasattr(L, name), "libjova_hip.so does not export %s" % name
+    assert sorted(decls) == _lib.EXPORTS
+    assert L.jova_abi_version() == 1
+    for name, sig in _lib._SIGS.items():
+        assert len(sig) == decls[name], "%s: binding has %d args, header %d" % (name, len(sig), decls[name])
+    assert isinstance(L.jova_nonsat_workspace_bytes(ctypes.c_int64(1000)), int)
+
+
+def test_abi_argument_errors_are_reported_without_a_gpu():
+    from jova_amd import _lib
+    with pytest.raises(RuntimeError, match="f_in"):
+        _lib.call("jova_graphconv_fwd", None, 0, 10, 500, 64, None, None, None, None, 1, None, None, None)
+    with pytest.raises(RuntimeError, match="unit stride"):
+        _lib.call("jova_gemm_f32", ctypes.c_void_p(16), 3, 3, ctypes.c_void_p(16), 1, 4, ctypes.c_void_p(16), 4, 4, 4,
+                  4, 1.0, None, None, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, None)
+
+
+def test_state_dict_matches_reference_manifest():
+    """Same keys and shapes as the reference's create_integrated_net at the tuned config => .mod files load as is."""
+    from jova_amd.train import TUNED_DAVIS_HPARAMS, count_parameters, create_integrated_net
+    man = json.load(open(os.path.join(H.GOLDEN, "manifest_tuned.json")))
+    net = create_integrated_net(TUNED_DAVIS_HPARAMS, {})
+    sd = net.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == man["state_dict"]
+    assert count_parameters(net) == man["n_trainable"] == 4900207
+
+
+def test_product_path_refuses_cpu_tensors():
+    from jova_amd.nn.layers import GraphPool
+    z = H.load("index_toy4")
+    gl = H.oracle_glist(H.unpack_mols(z), torch.zeros(int(z["nodes"].shape[0]), 8))
+    with pytest.raises(RuntimeError, match="GPU"):
+        GraphPool()(gl)
