@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Benchmark of the JOVA multi-view DTI training hot path on MI355X (contract: see the task statement / DESIGN.md).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A step = zero_grad -> forward -> MSELoss(out*w, y) -> backward -> (gradient all-reduce) -> SGD update of the tuned
+Davis joint-view model (ecfp8-gconv__pcnn2d, B = 128 per GPU) on a synthetic Davis-shaped batch that is already
+resident in HBM.  Rank 0 prints ONE JSON line: training pairs/s of the whole job, plus
+  roofline      the dominant kernel of the step (fp32 MFMA GEMM), timed live with HIP events on its stream;
+  graph_roofline  the graph kernels on the config-4 stress batch (4096 molecules), HBM roofline;
+  cpu_baseline  the oracle (CPU restatement of the reference path) timed on this box's host cores, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from jova_amd import synth                                      # noqa: E402
+from jova_amd.data.collate import collate_pairs                 # noqa: E402
+from jova_amd.feat.mol_graphs import ConvMol                    # noqa: E402
+from jova_amd.nn import functional as F_                        # noqa: E402
+from jova_amd.train import TUNED_DAVIS_HPARAMS, Trainer, count_parameters, create_integrated_net   # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32) dense peak
+
+
+def build_batches(pool, conv_mols, hp, device, n_batches, seed, prot2vec):
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n_batches):
+        mi, pi, y, w = pool.sample_pairs(rng, hp["tr_batch_size"])
+        out.append(collate_pairs(pool, conv_mols, mi, pi, y, w, device, prot2vec))
+    return out
+
+
+def cpu_baseline(pool, hp, batch_ids, state_dict, n_steps, threads):
+    """Oracle (fp32 CPU restatement of the reference path): fwd + bwd + SGD on the same kind of batch."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import mol_graphs as og
+    from oracle import nn_ref as R
+    torch.set_num_threads(threads)
+    mi, pi, y, w = batch_ids
+    t_col = time.perf_counter()
+    b = og.agglomerate([og.SortedMol(*pool.mols[i]) for i in mi])
+    gl = og.gconv_input_list(b)
+    glist = [torch.from_numpy(gl[0]), torch.from_numpy(gl[1]), torch.from_numpy(gl[2]), gl[3]] + \
+            [torch.from_numpy(a) for a in gl[4:]]
+    idx = og.embedding_indices([pool.prot_names[i] for i in pi], pool.protein_profile, fill_val=pool.vocab)
+    t_col = time.perf_counter() - t_col
+    batch = dict(ecfp=torch.from_numpy(pool.ecfp[mi]), glist=glist, prot_idx=torch.from_numpy(idx))
+    p = {k: (v.detach().cpu().clone().requires_grad_(v.is_floating_point() and "running" not in k))
+         for k, v in state_dict.items()}
+    yt, wt = torch.from_numpy(y).float(), torch.from_numpy(w).float()
+    lr, wd = hp["optimizer__global__lr"], hp["optimizer__global__weight_decay"]
+    times = []
+    for step in range(n_steps + 1):
+        t0 = time.perf_counter()
+        out, _ = R.dti_forward(p, batch, hp["attn_heads"], hp["prot"]["pcnn_num_layers"], len(hp["lin_dims"]))
+        loss = R.mse_loss(out, wt, yt)
+        loss.backward()
+        with torch.no_grad():
+            for v in p.values():
+                if v.requires_grad:
+                    if v.grad is not None:
+                        v -= lr * (v.grad + wd * v)
+                        v.grad = None
+        if step > 0:
+            times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return dict(value=round(hp["tr_batch_size"] / med, 2), unit="pairs/s", cores=threads, kind="port",
+                sample="%d timed fwd+bwd+SGD steps (after 1 warm-up) of the fp32 oracle on one Davis-shaped batch of %d "
+                       "pairs, median %.2f s/step; oracle collate %.1f ms/batch not included"
+                       % (n_steps, hp["tr_batch_size"], med, t_col * 1e3))
+
+
+def graph_stress(device, reps=20):
+    """Config 4: 4096 molecules (~246 k atoms, degree <= 10): graph kernels against the HBM roofline."""
+    from jova_amd.data.collate import process_gconv_view_data
+    from jova_amd.nn.layers import GraphConvLayer, GraphPool
+    pool = synth.SyntheticPool("graph4k", seed=1)
+    mols = [ConvMol(f, a, smiles=str(i)) for i, (f, a) in enumerate(pool.mols)]
+    glist = process_gconv_view_data(mols, device)
+    n = glist[0].shape[0]
+    e = sum(int(a.numel()) for a in glist[4:])
+    conv1, conv2, gp = GraphConvLayer(75, 64).to(device), GraphConvLayer(64, 64).to(device), GraphPool()
+    x2 = torch.randn(n, 64, device=device).relu_()
+    res = []
+
+    def timed(name, fn, nbytes):
+        fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        res.append(dict(kernel=name, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(gbs / HBM_PEAK_GBS, 4), us=round(ms * 1e3, 1), algorithmic_bytes=int(nbytes)))
+
+    wbytes = 4 * 21 * 65 * 64
+    with torch.no_grad():
+        # layer 1 reads int64 atom features (8 B) as the reference's collator delivers them
+        timed("graphconv_fwd_l1(int64 atoms 75->64)", lambda: conv1(glist), 8 * n * 75 + 4 * (n * 64 + e) + 4 * 21 * 76 * 64)
+        gl2 = [x2] + glist[1:]
+        timed("graphconv_fwd_l2(64->64)", lambda: conv2(gl2), 4 * (n * 64 + n * 64 + e) + wbytes)
+        timed("graphpool_fwd(64)", lambda: gp(gl2), 4 * (2 * n * 64 + e) + n * 64)
+    return dict(workload="graph4k: 4096 molecules, %d atoms, %d directed edges" % (n, e), kernels=res)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph-stress", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=device)
+        pg = torch.distributed.group.WORLD
+
+    hp = dict(TUNED_DAVIS_HPARAMS)
+    pool = synth.SyntheticPool("davis", seed=1)
+    conv_mols = [ConvMol(f, a, smiles=str(i)) for i, (f, a) in enumerate(pool.mols)]
+    torch.manual_seed(1)                                   # identical initial weights on every rank
+    model = create_integrated_net(hp, pool.protein_profile).to(device).train()
+    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    trainer = Trainer(model, hp, world_size=world, process_group=pg)
+    prot2vec = model[0].models[2][0]
+    batches = build_batches(pool, conv_mols, hp, device, 8, seed=1000 + rank, prot2vec=prot2vec)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.step(batches[i % len(batches)])
+    F_.PROBE["ffn1_fwd"] = []
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, _ = trainer.step(batches[i % len(batches)])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    probe = F_.PROBE.pop("ffn1_fwd")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+    if not np.isfinite(final_loss):
+        raise SystemExit("non-finite loss")
+
+    bsz = hp["tr_batch_size"]
+    pairs_per_s = args.steps * bsz * world / elapsed
+    # dominant kernel: the fp32 MFMA GEMM; probe = the FFN linear1 launch (largest single launch of the step)
+    flops = sum(f for _, _, f in probe)
+    ms = sum(a.elapsed_time(b) for a, b, _ in probe)
+    tfl = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    roofline = dict(kernel="gemm_f32_kernel<K-contig,K-contig> (JointAttention FFN linear1, [S*B,512]x[512,2048]+bias+ReLU)",
+                    bound="mfma", achieved=round(tfl, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(tfl / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                    launches=len(probe), avg_us=round(ms * 1e3 / max(len(probe), 1), 1))
+    line = dict(metric="DTI training pairs/sec (fwd+bwd, whole node) + achieved HBM GB/s fraction",
+                value=round(pairs_per_s, 1), unit="pairs/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
+                vs_baseline=None, dtype="f32", data="synthetic",
+                config=dict(workload="Davis DTI joint-view model (ecfp8-gconv__pcnn2d, tuned hparams) fwd+bwd+SGD, "
+                                     "B=128 per GPU, synthetic Davis-shaped batches resident in HBM",
+                            global_batch=bsz * world, parallelism="dp%d" % world,
+                            trainable_params=count_parameters(model)),
+                final_loss=round(final_loss, 6), roofline=roofline)
+    if rank == 0 and world == 1:
+        if not args.no_graph_stress:
+            line["graph_roofline"] = graph_stress(device)
+        if not args.no_cpu_baseline:
+            r = np.random.RandomState(1000)
+            threads = min(os.cpu_count() or 1, 16)
+            line["cpu_baseline"] = cpu_baseline(pool, hp, pool.sample_pairs(r, bsz), sd0, args.cpu_steps, threads)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -219,19 +219,29 @@ def _addr(t, offset=0):
     return ctypes.c_void_p(t.data_ptr() + 4 * offset)
 
 
+PROBE = {}      # tag -> list of (start event, end event, flops): bench.py times one launch shape live (HIP events)
+
+
 def gemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha=1.0, bias=None, residual=None, ldr=0, relu=False, splitk=1,
-         nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0)):
+         nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), tag=None):
     """Thin wrapper over jova_gemm_f32; A, B, C, bias, residual are ctypes addresses (see _addr)."""
+    if tag is not None and tag in PROBE:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        gemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha, bias, residual, ldr, relu, splitk, nb1, nb2, sA, sB, sC)
+        e1.record()
+        PROBE[tag].append((e0, e1, 2.0 * M * N * K * nb1 * nb2))
+        return
     call("jova_gemm_f32", A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, float(alpha), bias, residual, ldr, int(relu),
          splitk, nb1, nb2, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], stream())
 
 
-def linear_fwd(x2d, w, b, out2d, relu=False, residual=None):
+def linear_fwd(x2d, w, b, out2d, relu=False, residual=None, tag=None):
     """out[M,N] = x[M,K] @ w[N,K]^T + b (+ residual) (ReLU)."""
     M, K = x2d.shape
     N = w.shape[0]
     gemm(_addr(x2d), K, 1, _addr(w), 1, K, _addr(out2d), N, M, N, K, bias=P(b) if b is not None else None,
-         residual=_addr(residual) if residual is not None else None, ldr=N, relu=relu)
+         residual=_addr(residual) if residual is not None else None, ldr=N, relu=relu, tag=tag)
 
 
 def linear_bwd_data(dy2d, w, dx2d, residual=None):
@@ -490,7 +500,7 @@ class JointAttentionFunction(torch.autograd.Function):
             mr1 = _empty((T, 2), ref)
             call("jova_layernorm_fwd", P(x), P(xp), P(attn_g), P(attn_b), T, L, 1e-5, P(x1), P(mr1), stream())
             hid = _empty((T, w1.shape[0]), ref)
-            linear_fwd(x1, w1, b1, hid, relu=True)
+            linear_fwd(x1, w1, b1, hid, relu=True, tag="ffn1_fwd")
             f = _empty((T, L), ref)
             linear_fwd(hid, w2, b2, f)
             x2 = _empty((T, L), ref)
