@@ -82,7 +82,7 @@ def cpu_baseline(pool, hp, batch_ids, state_dict, n_steps, threads):
                        % (n_steps, hp["tr_batch_size"], med, t_col * 1e3))
 
 
-def graph_stress(device, reps=20):
+def graph_stress(device, reps=20, full=False):
     """Config 4: 4096 molecules (~246 k atoms, degree <= 10): graph kernels against the HBM roofline."""
     from jova_amd.data.collate import process_gconv_view_data
     from jova_amd.nn.layers import GraphConvLayer, GraphPool
@@ -109,12 +109,29 @@ def graph_stress(device, reps=20):
                         frac=round(gbs / HBM_PEAK_GBS, 4), us=round(ms * 1e3, 1), algorithmic_bytes=int(nbytes)))
 
     wbytes = 4 * 21 * 65 * 64
+    gl2 = [x2] + glist[1:]
     with torch.no_grad():
-        # layer 1 reads int64 atom features (8 B) as the reference's collator delivers them
-        timed("graphconv_fwd_l1(int64 atoms 75->64)", lambda: conv1(glist), 8 * n * 75 + 4 * (n * 64 + e) + 4 * 21 * 76 * 64)
-        gl2 = [x2] + glist[1:]
+        # layer 1: the batch's int64 atom features are converted to fp32 once per batch (cached on the topology),
+        # so the per-step kernel reads 4-byte features: algorithmic bytes as SURVEY.md section 8d
+        timed("graphconv_fwd_l1(75->64)", lambda: conv1(glist), 4 * (n * 75 + n * 64 + e) + 4 * 21 * 76 * 64)
         timed("graphconv_fwd_l2(64->64)", lambda: conv2(gl2), 4 * (n * 64 + n * 64 + e) + wbytes)
         timed("graphpool_fwd(64)", lambda: gp(gl2), 4 * (2 * n * 64 + e) + n * 64)
+    if full:
+        # backward kernels: parameters get .grad buffers first so the kernels accumulate in place (as in the trainer)
+        for m in (conv1, conv2):
+            for prm in m.parameters():
+                prm.grad = torch.zeros_like(prm)
+        x2g = x2.clone().requires_grad_(True)
+        gl2g = [x2g] + glist[1:]
+        g64 = torch.randn(n, 64, device=device)
+        y1, y2, yp = conv1(glist), conv2(gl2g), gp(gl2g)
+
+        def bwd(y):
+            x2g.grad = None
+            y.backward(g64, retain_graph=True)
+        timed("graphconv_bwd_l1(dW only)", lambda: bwd(y1), 4 * (n * 64 + n * 75 + e) + 2 * 4 * 21 * 76 * 64)
+        timed("graphconv_bwd_l2(dW + dX, 2 launches)", lambda: bwd(y2), 4 * (n * 64 + 3 * n * 64 + e) + 2 * wbytes)
+        timed("graphpool_bwd(64)", lambda: bwd(yp), 4 * (2 * n * 64 + e) + n * 64)
     return dict(workload="graph4k: 4096 molecules, %d atoms, %d directed edges" % (n, e), kernels=res)
 
 

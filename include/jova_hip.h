@@ -26,20 +26,28 @@ const char* jova_last_error(void);
 int jova_abi_version(void);
 
 /* ---- GraphConvLayer: jova/nn/layers.py:282-347 ---------------------------------------------------------------
- * atoms [N, f_in] (int64 when atoms_is_i64, the featuriser's dtype for layer 1; else fp32), sorted degree-major as
+ * atoms [N, f_in] with row stride ld_atoms (int64 when atoms_is_i64, the featuriser's dtype for layer 1; else fp32),
+ * sorted degree-major as
  * ConvMol.agglomerate_mols leaves them (jova/feat/mol_graphs.py:290-296); deg_slice int64 [11,2] (start,size);
  * adj: HOST array of 10 device pointers, adj[d-1] = int32 [n_d, d]; weight/bias: HOST arrays of 21 device pointers
  * in linear_layers order (rel_1, self_1, ..., rel_10, self_10, self_0), weight[k] = [f_out, f_in].
  * out [N, f_out] = act( W_rel[d] . sum_nbr x + b_rel[d] + W_self[d] . x + b_self[d] ).
- * bn_stats (optional, fp64 [2, f_out]): column sum / sum of squares of `out` for the BatchNorm1d that follows. */
-int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t n_atoms, int f_in, int f_out,
+ * bn_stats (optional, fp64 [2, f_out]): column sum / sum of squares of `out` for the BatchNorm1d that follows.
+ * packed_ws: scratch of jova_graphconv_workspace_floats(f_in, f_out) floats. */
+int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t ld_atoms, int64_t n_atoms, int f_in, int f_out,
                        const int64_t* deg_slice, const int32_t* const* adj, const float* const* weight,
-                       const float* const* bias, int relu, float* out, double* bn_stats, void* stream);
+                       const float* const* bias, int relu, float* out, double* bn_stats, float* packed_ws,
+                       void* stream);
+/* int64 atom features [n, f] -> fp32 rows padded with zeros to ld floats (ld % 4 == 0 enables 16-byte row loads in
+ * jova_graphconv_fwd / _bwd; done once per batch: the features of a batch never change) */
+int jova_atoms_to_f32(const int64_t* atoms, int64_t n_atoms, int f, int ld, float* out, void* stream);
+/* floats of scratch `packed_ws` (the weights re-packed into MFMA fragment order, rebuilt every call) */
+size_t jova_graphconv_workspace_floats(int f_in, int f_out);
 
 /* Backward of the above.  dy [N, f_out]; y = forward output when the layer applied ReLU (mask), else NULL.
  * dweight/dbias: HOST arrays of 21 device pointers, accumulate.  dx [N, f_in] (optional, fp32 atoms only) needs
  * gbuf [N, f_in] scratch and `weight`.  sym_flag: device int from jova_adj_symmetry (NULL or 0 -> atomic scatter). */
-int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t n_atoms, int f_in, int f_out,
+int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t ld_atoms, int64_t n_atoms, int f_in, int f_out,
                        const int64_t* deg_slice, const int32_t* const* adj, const float* const* weight,
                        const float* dy, const float* y_or_null, float* const* dweight, float* const* dbias,
                        float* dx_or_null, float* gbuf_or_null, const int* sym_flag, void* stream);
@@ -50,11 +58,13 @@ int jova_adj_symmetry(int64_t n_atoms, const int64_t* deg_slice, const int32_t* 
 
 /* ---- GraphPool: jova/nn/layers.py:356-393 -------------------------------------------------------------------
  * out[i] = max(x[i], max over neighbours); ties -> first candidate (self, then adjacency order) like torch.max.
- * argmax uint8 [N, f]: 0 = self, k = k-th neighbour. */
+ * argmax uint8 [N, f]: 0 = self, k = k-th neighbour.  Backward: sym_flag = device flag of jova_adj_symmetry;
+ * host_knows_symmetric = 1 when the caller has read that flag as 1 (selects the pure-gather kernel, no memset). */
 int jova_graphpool_fwd(const float* x, int64_t n_atoms, int f, const int64_t* deg_slice, const int32_t* const* adj,
                        float* out, uint8_t* argmax, void* stream);
 int jova_graphpool_bwd(const float* dy, const uint8_t* argmax, int64_t n_atoms, int f, const int64_t* deg_slice,
-                       const int32_t* const* adj, float* dx, const int* sym_flag, int reserved, void* stream);
+                       const int32_t* const* adj, float* dx, const int* sym_flag, int host_knows_symmetric,
+                       void* stream);
 
 /* ---- GraphGather2D: jova/nn/layers.py:427-437 ---------------------------------------------------------------
  * mol_off int32 [batch+1] = prefix sums of n_atoms_lst; out [a_max, batch, g] = zero-padded contiguous chunks. */

@@ -13,8 +13,9 @@ LIB_PATH = os.path.join(_HERE, "libjova_hip.so")
 
 # signature codes: p = pointer, i = int, q = int64, f = float, Q = uint64
 _SIGS = {
-    "jova_graphconv_fwd": "piqiipppp" + "ippp",
-    "jova_graphconv_bwd": "piqiippp" + "pppp" + "pppp",
+    "jova_graphconv_fwd": "piqqiipppp" + "ipppp",
+    "jova_atoms_to_f32": "pqiipp",
+    "jova_graphconv_bwd": "piqqiippp" + "pppp" + "pppp",
     "jova_adj_symmetry": "qpppp",
     "jova_graphpool_fwd": "pqipp" + "ppp",
     "jova_graphpool_bwd": "ppqipp" + "ppip",
@@ -45,7 +46,8 @@ _SIGS = {
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "q": ctypes.c_int64, "f": ctypes.c_float, "Q": ctypes.c_uint64}
 
-EXPORTS = sorted(list(_SIGS) + ["jova_last_error", "jova_abi_version", "jova_nonsat_workspace_bytes"])
+EXPORTS = sorted(list(_SIGS) + ["jova_last_error", "jova_abi_version", "jova_nonsat_workspace_bytes",
+                                "jova_graphconv_workspace_floats"])
 
 _lib = None
 
@@ -67,6 +69,8 @@ def lib():
         L.jova_abi_version.restype = ctypes.c_int
         L.jova_nonsat_workspace_bytes.restype = ctypes.c_size_t
         L.jova_nonsat_workspace_bytes.argtypes = [ctypes.c_int64]
+        L.jova_graphconv_workspace_floats.restype = ctypes.c_size_t
+        L.jova_graphconv_workspace_floats.argtypes = [ctypes.c_int, ctypes.c_int]
         _lib = L
     return _lib
 

@@ -70,8 +70,19 @@ __device__ __forceinline__ void mfma_tile_lds(const float* a, int a_si, int a_sk
     const int i = lane & 31, h = lane >> 5;
     const float* ap = a + i * a_si + h * a_sk;
     const float* bp = b + h * b_sk + i * b_sj;
-#pragma unroll 4
-    for (int k = 0; k < K; k += 2) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k * a_sk], bp[k * b_sk], acc, 0, 0, 0);
+    // 8 k-pairs of operands are read ahead of their 8 dependent MFMAs so the LDS round trip is paid once per group
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = min(k0 + 2 * u, K - 2);
+            av[u] = ap[k * a_sk];
+            bv[u] = bp[k * b_sk];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float x = (k0 + 2 * u < K) ? av[u] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, bv[u], acc, 0, 0, 0);
+        }
     }
 }

@@ -44,127 +44,254 @@ __device__ __forceinline__ bool locate_tiles(const long long* __restrict__ deg_s
 template <typename T> struct AccT { typedef float type; };
 template <> struct AccT<long long> { typedef long long type; };
 
-// As[r][0..kcols) <- sum over the `deg` neighbours of bucket-row (lrow0 + r) of x[nbr][:]  (zero padded)
-template <typename TIn>
-__device__ __forceinline__ void stage_nbr_sum(const TIn* __restrict__ x, int n_atoms, int f_in,
-                                              const int* __restrict__ adj_d, int deg, long long lrow0, int rows,
-                                              float* As, int KS, int kcols, int wave, int lane) {
-    typedef typename AccT<TIn>::type acc_t;
+// ------------------------------------------------------------------------------------------------ tile staging
+// Both A operands of a tile at once: Ss[r][:] = sum of the neighbour rows of atom r, Xs[r][:] = its own row.
+// All loads are unconditional (indices / rows clamped, results zeroed by selects) so a wave keeps many rows in
+// flight; the adjacency indices of a row-group are fetched before any feature row.
+//
+// Fast form: fp32 rows that are a multiple of 4 wide.  16 lanes (f <= 64) or 32 lanes (f <= 128) cover one row with
+// float4 loads, so one wave instruction moves 4 (or 2) whole rows.
+__device__ __forceinline__ void stage_tile_vec4(const float* __restrict__ x, int n_atoms, int f_in, int ldx,
+                                                const int* __restrict__ adj_d, int deg, long long lrow0,
+                                                long long row0, int rows, float* Ss, float* Xs, int KS, int kcols,
+                                                int wave, int lane) {
+    const int lsh = f_in <= 64 ? 4 : 5;
+    const int rpi = 64 >> lsh;
+    const int sub = lane >> lsh, c4 = (lane & ((1 << lsh) - 1)) * 4;
+    const bool cok = c4 < f_in;
+    const int cc = cok ? c4 : 0;
 #pragma unroll 2
-    for (int rr = 0; rr < 16; ++rr) {
-        const int r = wave * 16 + rr;
-        acc_t s0 = 0, s1 = 0;
-        if (r < rows) {
-            const int* arow = adj_d + (lrow0 + r) * deg;
-            for (int n = 0; n < deg; ++n) {
-                int j = arow[n];
-                j = min(max(j, 0), n_atoms - 1);
-                const TIn* xr = x + (long long)j * f_in;
-                if (lane < f_in) s0 += xr[lane];
-                if (lane + 64 < f_in) s1 += xr[lane + 64];
+    for (int it = 0; it < 16; it += rpi) {
+        const int r = wave * 16 + it + sub;
+        const bool rok = r < rows;
+        const int rc = rok ? r : rows - 1;
+        const float4 self = *reinterpret_cast<const float4*>(x + (row0 + rc) * ldx + cc);
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (deg > 0) {
+            const int* arow = adj_d + (lrow0 + rc) * deg;
+            for (int n = 0; n < deg; n += 4) {
+                int j[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) j[u] = min(max(arow[min(n + u, deg - 1)], 0), n_atoms - 1);
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + (long long)j[u] * ldx + cc);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float m = (n + u < deg) ? 1.f : 0.f;
+                    sum.x += m * v[u].x; sum.y += m * v[u].y; sum.z += m * v[u].z; sum.w += m * v[u].w;
+                }
             }
         }
-        if (lane < kcols) As[r * KS + lane] = (float)s0;
-        if (lane + 64 < kcols) As[r * KS + lane + 64] = (float)s1;
-    }
-}
-
-// As[r][0..kcols) <- x[row0 + r][:]  (zero padded rows/cols)
-template <typename TIn>
-__device__ __forceinline__ void stage_rows(const TIn* __restrict__ x, int f_in, long long row0, int rows, float* As,
-                                           int KS, int kcols, int wave, int lane) {
-#pragma unroll 4
-    for (int rr = 0; rr < 16; ++rr) {
-        const int r = wave * 16 + rr;
-        float v0 = 0.f, v1 = 0.f;
-        if (r < rows) {
-            const TIn* xr = x + (row0 + r) * f_in;
-            if (lane < f_in) v0 = (float)xr[lane];
-            if (lane + 64 < f_in) v1 = (float)xr[lane + 64];
+        const bool ok = rok && cok;
+        if (c4 < kcols) {
+            float* sp = Ss + r * KS + c4;
+            float* xp = Xs + r * KS + c4;
+            sp[0] = ok ? sum.x : 0.f; sp[1] = ok ? sum.y : 0.f; sp[2] = ok ? sum.z : 0.f; sp[3] = ok ? sum.w : 0.f;
+            xp[0] = ok ? self.x : 0.f; xp[1] = ok ? self.y : 0.f; xp[2] = ok ? self.z : 0.f; xp[3] = ok ? self.w : 0.f;
         }
-        if (lane < kcols) As[r * KS + lane] = v0;
-        if (lane + 64 < kcols) As[r * KS + lane + 64] = v1;
     }
 }
 
-// Ws[n][0..kcols) <- W[n0 + n][:]  for n in [0,64)  (zero padded)
-__device__ __forceinline__ void stage_weight(const float* __restrict__ W, int f_in, int f_out, int n0, float* Ws,
-                                             int KS, int kcols, int wave, int lane) {
-    stage_rows<float>(W, f_in, n0, min(64, f_out - n0), Ws, KS, kcols, wave, lane);
+// Generic form (int64 atoms of layer 1, or rows that are not 16-byte multiples): lane -> column (lane, lane + 64),
+// four rows of the wave's 16 in flight together.
+template <typename TIn>
+__device__ __forceinline__ void stage_tile_generic(const TIn* __restrict__ x, int n_atoms, int f_in, int ldx,
+                                                   const int* __restrict__ adj_d, int deg, long long lrow0,
+                                                   long long row0, int rows, float* Ss, float* Xs, int KS, int kcols,
+                                                   int wave, int lane) {
+    typedef typename AccT<TIn>::type acc_t;
+    const bool c0ok = lane < f_in, c1ok = lane + 64 < f_in;
+    const int c0 = c0ok ? lane : 0, c1 = c1ok ? lane + 64 : 0;
+    for (int rq = 0; rq < 16; rq += 4) {
+        acc_t s0[4], s1[4];
+        TIn x0[4], x1[4];
+        int rc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = wave * 16 + rq + u;
+            rc[u] = r < rows ? r : rows - 1;
+            const TIn* xr = x + (row0 + rc[u]) * ldx;
+            x0[u] = xr[c0];
+            x1[u] = xr[c1];
+            s0[u] = 0;
+            s1[u] = 0;
+        }
+        for (int n = 0; n < deg; ++n) {
+            int j[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) j[u] = min(max(adj_d[(lrow0 + rc[u]) * deg + n], 0), n_atoms - 1);
+            TIn a0[4], a1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const TIn* xr = x + (long long)j[u] * ldx;
+                a0[u] = xr[c0];
+                a1[u] = xr[c1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s0[u] += a0[u]; s1[u] += a1[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = wave * 16 + rq + u;
+            const bool rok = r < rows;
+            if (lane < kcols) {
+                Ss[r * KS + lane] = (rok && c0ok) ? (float)s0[u] : 0.f;
+                Xs[r * KS + lane] = (rok && c0ok) ? (float)x0[u] : 0.f;
+            }
+            if (lane + 64 < kcols) {
+                Ss[r * KS + lane + 64] = (rok && c1ok) ? (float)s1[u] : 0.f;
+                Xs[r * KS + lane + 64] = (rok && c1ok) ? (float)x1[u] : 0.f;
+            }
+        }
+    }
+}
+
+template <typename TIn>
+__device__ __forceinline__ void stage_tile(const TIn* __restrict__ x, int n_atoms, int f_in, int ldx,
+                                           const int* __restrict__ adj_d, int deg, long long lrow0, long long row0,
+                                           int rows, float* Ss, float* Xs, int KS, int kcols, int wave, int lane) {
+    stage_tile_generic<TIn>(x, n_atoms, f_in, ldx, adj_d, deg, lrow0, row0, rows, Ss, Xs, KS, kcols, wave, lane);
+}
+template <>
+__device__ __forceinline__ void stage_tile<float>(const float* __restrict__ x, int n_atoms, int f_in, int ldx,
+                                                  const int* __restrict__ adj_d, int deg, long long lrow0,
+                                                  long long row0, int rows, float* Ss, float* Xs, int KS, int kcols,
+                                                  int wave, int lane) {
+    // rows padded to a multiple of 4 floats (ldx) are read whole with 16-byte loads; the pad columns hold zeros
+    if ((ldx & 3) == 0 && ((((unsigned long long)x) & 15) == 0))
+        stage_tile_vec4(x, n_atoms, (f_in + 3) & ~3, ldx, adj_d, deg, lrow0, row0, rows, Ss, Xs, KS, kcols, wave, lane);
+    else
+        stage_tile_generic<float>(x, n_atoms, f_in, ldx, adj_d, deg, lrow0, row0, rows, Ss, Xs, KS, kcols, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// Weights are re-packed once per call into MFMA B-fragment order,
+//   Wp[w][p][cb][lane] = W_w[32*cb + (lane & 31)][2*p + (lane >> 5)]   (zero padded),
+// so the B operand of k-pair p is ONE coalesced 256-byte load per wave, served from L2 (the 21 matrices total
+// < 0.5 MB) and prefetched 8 k-pairs ahead in registers: no LDS and no long-lived registers for the weights,
+// which keeps the kernel at 4 workgroups per CU while tiles of other workgroups are in their gather phase.
+__global__ void graphconv_pack_kernel(GcParams P, int f_in, int f_out, int kh, int ncb, float* __restrict__ wp) {
+    const long long total = 21ll * kh * ncb * 64;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(e & 63);
+        long long q = e >> 6;
+        const int cb = (int)(q % ncb);
+        q /= ncb;
+        const int p = (int)(q % kh), w = (int)(q / kh);
+        const int col = 32 * cb + (lane & 31), k = 2 * p + (lane >> 5);
+        wp[e] = (col < f_out && k < f_in) ? P.w[w][(long long)col * f_in + k] : 0.f;
+    }
+}
+
+// int64 atom features (what the featuriser / collator delivers for layer 1) -> fp32 rows padded to `ld` floats
+__global__ void atoms_to_f32_kernel(const long long* __restrict__ x, long long n, int f, int ld,
+                                    float* __restrict__ out) {
+    const long long total = n * ld;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / ld;
+        const int c = (int)(e - r * ld);
+        out[e] = c < f ? (float)x[r * f + c] : 0.f;
+    }
+}
+
 template <typename TIn>
-__global__ void __launch_bounds__(256)
-graphconv_fwd_kernel(const TIn* __restrict__ x, int n_atoms, int f_in, int f_out,
-                     const long long* __restrict__ deg_slice, GcParams P, int relu, float* __restrict__ out,
-                     double* __restrict__ stats) {
+__global__ void __launch_bounds__(256, (sizeof(TIn) == 8 ? 3 : 4))
+graphconv_fwd_kernel(const TIn* __restrict__ x, int n_atoms, int f_in, int ldx, int f_out,
+                     const long long* __restrict__ deg_slice, GcParams P, const float* __restrict__ wp, int kh,
+                     int ncb, int relu, float* __restrict__ out, double* __restrict__ stats, int group) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int deg, tile0, ntile;
     long long bstart, bsize;
-    if (!locate_tiles(deg_slice, blockIdx.x, 1, deg, bstart, bsize, tile0, ntile)) return;
+    if (!locate_tiles(deg_slice, blockIdx.x, group, deg, bstart, bsize, tile0, ntile)) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int KP = (f_in + 1) & ~1;          // even K for the 2-deep MFMA step
-    const int KS = KP | 1;                   // odd LDS row stride: conflict-free ds_read_b32 down a column
-    float* As = smem;
-    float* Ws = smem + TM * KS;
-    const long long lrow0 = (long long)tile0 * TM;
-    const int rows = (int)min((long long)TM, bsize - lrow0);
-    const long long row0 = bstart + lrow0;
-    const int n0 = blockIdx.y * 64;
+    const int KC = 2 * kh;                   // staged columns (zero padded beyond f_in)
+    const int KS = KC + 1;                   // odd LDS row stride: conflict-free ds_read_b32 down a column
+    float* Ss = smem;
+    float* Xs = smem + TM * KS;
     const int wr = wave >> 1, wc = wave & 1;
+    const int i = lane & 31, h = lane >> 5;
+    const int cb = blockIdx.y * 2 + wc;      // 32-column block of this wave
     const int w_rel = 2 * (deg - 1), w_self = deg == 0 ? 20 : 2 * (deg - 1) + 1;
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-    if (deg > 0) {
-        stage_nbr_sum<TIn>(x, n_atoms, f_in, P.adj[deg - 1], deg, lrow0, rows, As, KS, KP, wave, lane);
-        stage_weight(P.w[w_rel], f_in, f_out, n0, Ws, KS, KP, wave, lane);
-        __syncthreads();
-        mfma_tile_lds(As + 32 * wr * KS, KS, 1, Ws + 32 * wc * KS, 1, KS, KP, acc, lane);
-        __syncthreads();
-    }
-    stage_rows<TIn>(x, f_in, row0, rows, As, KS, KP, wave, lane);
-    stage_weight(P.w[w_self], f_in, f_out, n0, Ws, KS, KP, wave, lane);
-    __syncthreads();
-    mfma_tile_lds(As + 32 * wr * KS, KS, 1, Ws + 32 * wc * KS, 1, KS, KP, acc, lane);
-
-    const int col = n0 + 32 * wc + (lane & 31);
+    const int col = 32 * cb + i;
+    const bool colok = col < f_out && cb < ncb;
+    const int cbc = cb < ncb ? cb : ncb - 1;
+    const float* wrel = wp + (((long long)(deg > 0 ? w_rel : w_self) * kh) * ncb + cbc) * 64 + lane;
+    const float* wself = wp + (((long long)w_self * kh) * ncb + cbc) * 64 + lane;
+    const long long wstep = (long long)ncb * 64;
     float bias = 0.f;
-    if (col < f_out) {
+    if (colok) {
         bias = P.b[w_self][col];
         if (deg > 0) bias += P.b[w_rel][col];
     }
-    float s = 0.f, q = 0.f;
+    double s = 0.0, q = 0.0;
+
+    for (int t = 0; t < ntile; ++t) {
+        const long long lrow0 = (long long)(tile0 + t) * TM;
+        const int rows = (int)min((long long)TM, bsize - lrow0);
+        const long long row0 = bstart + lrow0;
+        __syncthreads();                         // the previous tile's fragment reads are done
+        stage_tile<TIn>(x, n_atoms, f_in, ldx, deg > 0 ? P.adj[deg - 1] : nullptr, deg, lrow0, row0, rows, Ss, Xs, KS,
+                        KC, wave, lane);
+        __syncthreads();
+        f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = 32 * wr + mfma32_row(r, lane);
-        float v = acc[r] + bias;
-        if (relu) v = fmaxf(v, 0.f);
-        if (row < rows && col < f_out) {
-            out[(row0 + row) * f_out + col] = v;
-            s += v;
-            q += v * v;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* sp = Ss + (32 * wr + i) * KS + h;
+        const float* xp = Xs + (32 * wr + i) * KS + h;
+        // two passes (neighbour sums x W_rel, own rows x W_self) over kh k-pairs, 8 at a time: the 8 A values come
+        // from LDS and the 8 B values from L2, both issued ahead of the 8 dependent MFMAs
+        for (int pass = deg > 0 ? 0 : 1; pass < 2; ++pass) {
+            const float* ap = pass == 0 ? sp : xp;
+            const float* bp = pass == 0 ? wrel : wself;
+            for (int p0 = 0; p0 < kh; p0 += 8) {
+                float a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int p = min(p0 + u, kh - 1);
+                    b[u] = bp[p * wstep];
+                    a[u] = ap[2 * p];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float av = (p0 + u < kh) ? a[u] : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u], acc, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * wr + mfma32_row(r, lane);
+            float v = acc[r] + bias;
+            if (relu) v = fmaxf(v, 0.f);
+            if (row < rows && colok) {
+                out[(row0 + row) * f_out + col] = v;
+                s += (double)v;
+                q += (double)v * (double)v;
+            }
         }
     }
     if (stats) {      // per-column sum / sum of squares for the BatchNorm that follows (fp64 accumulators)
         s += __shfl_xor(s, 32, 64);
         q += __shfl_xor(q, 32, 64);
-        if (lane < 32 && col < f_out) {
-            atomicAdd(&stats[col], (double)s);
-            atomicAdd(&stats[f_out + col], (double)q);
+        if (lane < 32 && colok) {
+            atomicAdd(&stats[col], s);
+            atomicAdd(&stats[f_out + col], q);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// Per tile: dZ = dY * (Y > 0);  dW_rel += dZ^T S, dW_self += dZ^T X, db += colsum(dZ);
-// NEED_DX: G = dZ W_rel -> gbuf, T = dZ W_self -> dx  (dx[i] += sum_{j in nbr(i)} G[j] is the second kernel).
+// Per tile: dZ = dY * (Y > 0);  dW_rel += dZ^T S, dW_self += dZ^T X, db += colsum(dZ)  (accumulated in registers over
+// the workgroup's `group` tiles, one atomic flush at the end);
+// NEED_DX: G = dZ W_rel -> gbuf, T = dZ W_self -> dx  (dx[i] += sum_{j in nbr(i)} G[j] is the second kernel);
+// the B operand of those two products is read straight from the weight matrices (row o, 32 consecutive columns:
+// coalesced, L2 resident).
 template <typename TIn, bool NEED_DX>
-__global__ void __launch_bounds__(256)
-graphconv_bwd_kernel(const TIn* __restrict__ x, int n_atoms, int f_in, int f_out,
+__global__ void __launch_bounds__(256, 2)
+graphconv_bwd_kernel(const TIn* __restrict__ x, int n_atoms, int f_in, int ldx, int f_out,
                      const long long* __restrict__ deg_slice, GcParams P, const float* __restrict__ dy,
                      const float* __restrict__ y, GcGrads Gd, float* __restrict__ gbuf, float* __restrict__ dx,
                      int group) {
@@ -178,10 +305,11 @@ graphconv_bwd_kernel(const TIn* __restrict__ x, int n_atoms, int f_in, int f_out
     const int KS = KC + 1;
     const int ZS = 65;
     float* Zs = smem;                          // [64 rows][65]  dZ tile
-    float* As = Zs + TM * ZS;                  // [64 rows][KS]  S or X tile
-    float* Ws = As + TM * KS;                  // [64 o][KS]     W_rel / W_self
+    float* Ss = Zs + TM * ZS;                  // [64 rows][KS]  neighbour sums
+    float* Xs = Ss + TM * KS;                  // [64 rows][KS]  own rows
     const int mt = wave & 1;
     const int nt0 = wave >> 1, nt1 = (wave >> 1) + 2;
+    const int i = lane & 31, h = lane >> 5;
     const int w_rel = 2 * (deg - 1), w_self = deg == 0 ? 20 : 2 * (deg - 1) + 1;
 
     f32x16 a_rel0, a_rel1, a_self0, a_self1;
@@ -194,64 +322,65 @@ graphconv_bwd_kernel(const TIn* __restrict__ x, int n_atoms, int f_in, int f_out
         const int rows = (int)min((long long)TM, bsize - lrow0);
         const long long row0 = bstart + lrow0;
         __syncthreads();                       // previous tile's LDS readers are done
-        for (int rr = 0; rr < 16; ++rr) {      // dZ tile: wave -> 16 rows, lane -> output column
+#pragma unroll 4
+        for (int rr = 0; rr < 16; ++rr) {      // dZ tile: wave -> 16 rows, lane -> output column (unconditional loads)
             const int r = wave * 16 + rr;
-            float v = 0.f;
-            if (r < rows && lane < f_out) {
-                v = dy[(row0 + r) * f_out + lane];
-                if (y && !(y[(row0 + r) * f_out + lane] > 0.f)) v = 0.f;
-            }
-            Zs[r * ZS + lane] = v;
+            const bool ok = r < rows && lane < f_out;
+            const long long off = (row0 + (r < rows ? r : rows - 1)) * f_out + (lane < f_out ? lane : 0);
+            float v = dy[off];
+            if (y) v = y[off] > 0.f ? v : 0.f;
+            Zs[r * ZS + lane] = ok ? v : 0.f;
         }
-        if (deg > 0) {
-            stage_nbr_sum<TIn>(x, n_atoms, f_in, P.adj[deg - 1], deg, lrow0, rows, As, KS, KC, wave, lane);
-            if (NEED_DX) stage_weight(P.w[w_rel], f_in, f_out, 0, Ws, KS, KC, wave, lane);
-        }
+        stage_tile<TIn>(x, n_atoms, f_in, ldx, deg > 0 ? P.adj[deg - 1] : nullptr, deg, lrow0, row0, rows, Ss, Xs, KS,
+                        KC, wave, lane);
         __syncthreads();
         if (tid < 64) {
             float s = 0.f;
             for (int r = 0; r < TM; ++r) s += Zs[r * ZS + tid];
             db_acc += s;
         }
+        // dW[o][k] += sum_row dZ[row][o] * A[row][k]
         if (deg > 0) {
-            // dW_rel[o][k] += sum_row dZ[row][o] * S[row][k]
-            if (nt0 < NT) mfma_tile_lds(Zs + 32 * mt, 1, ZS, As + 32 * nt0, KS, 1, TM, a_rel0, lane);
-            if (nt1 < NT) mfma_tile_lds(Zs + 32 * mt, 1, ZS, As + 32 * nt1, KS, 1, TM, a_rel1, lane);
-            if (NEED_DX) {
-                // G[row][k] = sum_o dZ[row][o] * W_rel[o][k]
+            if (nt0 < NT) mfma_tile_lds(Zs + 32 * mt, 1, ZS, Ss + 32 * nt0, KS, 1, TM, a_rel0, lane);
+            if (nt1 < NT) mfma_tile_lds(Zs + 32 * mt, 1, ZS, Ss + 32 * nt1, KS, 1, TM, a_rel1, lane);
+        }
+        if (nt0 < NT) mfma_tile_lds(Zs + 32 * mt, 1, ZS, Xs + 32 * nt0, KS, 1, TM, a_self0, lane);
+        if (nt1 < NT) mfma_tile_lds(Zs + 32 * mt, 1, ZS, Xs + 32 * nt1, KS, 1, TM, a_self1, lane);
+        if (NEED_DX) {
+            // G[row][k] = sum_o dZ[row][o] W_rel[o][k];  T[row][k] = sum_o dZ[row][o] W_self[o][k]
+#pragma unroll 1
+            for (int pass = deg > 0 ? 0 : 1; pass < 2; ++pass) {
+                const float* W = P.w[pass == 0 ? w_rel : w_self];
+                float* dst = pass == 0 ? gbuf : dx;
 #pragma unroll 1
                 for (int nt = nt0; nt < NT; nt += 2) {
                     f32x16 g;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) g[r] = 0.f;
-                    mfma_tile_lds(Zs + 32 * mt * ZS, ZS, 1, Ws + 32 * nt, KS, 1, 64, g, lane);
-                    const int k = 32 * nt + (lane & 31);
+                    const int k = 32 * nt + i;
+                    const bool kok = k < f_in;
+                    const float* wp = W + (kok ? k : 0);
+                    const float* zp = Zs + (32 * mt + i) * ZS + h;
+                    for (int o0 = 0; o0 < 64; o0 += 16) {
+                        float a[8], b[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int o = o0 + 2 * u + h;
+                            b[u] = wp[(long long)(o < f_out ? o : 0) * f_in];
+                            a[u] = zp[o0 + 2 * u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int o = o0 + 2 * u + h;
+                            const float bv = (kok && o < f_out) ? b[u] : 0.f;
+                            g = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv, g, 0, 0, 0);
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = 32 * mt + mfma32_row(r, lane);
-                        if (row < rows && k < f_in) gbuf[(row0 + row) * f_in + k] = g[r];
+                        if (row < rows && kok) dst[(row0 + row) * f_in + k] = g[r];
                     }
-                }
-            }
-            __syncthreads();
-        }
-        stage_rows<TIn>(x, f_in, row0, rows, As, KS, KC, wave, lane);
-        if (NEED_DX) stage_weight(P.w[w_self], f_in, f_out, 0, Ws, KS, KC, wave, lane);
-        __syncthreads();
-        if (nt0 < NT) mfma_tile_lds(Zs + 32 * mt, 1, ZS, As + 32 * nt0, KS, 1, TM, a_self0, lane);
-        if (nt1 < NT) mfma_tile_lds(Zs + 32 * mt, 1, ZS, As + 32 * nt1, KS, 1, TM, a_self1, lane);
-        if (NEED_DX) {
-#pragma unroll 1
-            for (int nt = nt0; nt < NT; nt += 2) {
-                f32x16 g;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) g[r] = 0.f;
-                mfma_tile_lds(Zs + 32 * mt * ZS, ZS, 1, Ws + 32 * nt, KS, 1, 64, g, lane);
-                const int k = 32 * nt + (lane & 31);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = 32 * mt + mfma32_row(r, lane);
-                    if (row < rows && k < f_in) dx[(row0 + row) * f_in + k] = g[r];
                 }
             }
         }
@@ -435,6 +564,111 @@ graphpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restri
     }
 }
 
+// ---- 16-lanes-per-row forms (f % 4 == 0): a wave works on 4 atoms at once with float4 loads, the first four
+// neighbour rows of each in flight together; used whenever the rows are 16-byte multiples (the model's f = 64).
+__device__ __forceinline__ void find_bucket(const long long* __restrict__ deg_slice, long long row, int& deg,
+                                            long long& lrow) {
+    deg = 0;
+    lrow = 0;
+#pragma unroll
+    for (int d = 0; d < NB; ++d) {
+        const long long s = deg_slice[2 * d], c = deg_slice[2 * d + 1];
+        if (row >= s && row < s + c) { deg = d; lrow = row - s; }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+graphpool_fwd_v4_kernel(const float* __restrict__ x, int n_atoms, int f, const long long* __restrict__ deg_slice,
+                        GcParams P, float* __restrict__ out, unsigned char* __restrict__ arg) {
+    const int l16 = threadIdx.x & 15;
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (row >= n_atoms) return;
+    int deg;
+    long long lrow;
+    find_bucket(deg_slice, row, deg, lrow);
+    const int* arow = deg > 0 ? P.adj[deg - 1] + lrow * deg : nullptr;
+    for (int c = 4 * l16; c < f; c += 64) {
+        float4 best = *reinterpret_cast<const float4*>(x + row * f + c);
+        int ax = 0, ay = 0, az = 0, aw = 0;
+        for (int n = 0; n < deg; n += 4) {
+            int j[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) j[u] = min(max(arow[min(n + u, deg - 1)], 0), n_atoms - 1);
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + (long long)j[u] * f + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (n + u < deg) {
+                    if (v[u].x > best.x) { best.x = v[u].x; ax = n + u + 1; }
+                    if (v[u].y > best.y) { best.y = v[u].y; ay = n + u + 1; }
+                    if (v[u].z > best.z) { best.z = v[u].z; az = n + u + 1; }
+                    if (v[u].w > best.w) { best.w = v[u].w; aw = n + u + 1; }
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(out + row * f + c) = best;
+        *reinterpret_cast<unsigned*>(arg + row * f + c) = (unsigned)ax | ((unsigned)ay << 8) | ((unsigned)az << 16) |
+                                                          ((unsigned)aw << 24);
+    }
+}
+
+// symmetric adjacency only (the host wrapper falls back to the generic kernel otherwise)
+__global__ void __launch_bounds__(256)
+graphpool_bwd_v4_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg, int n_atoms, int f,
+                        const long long* __restrict__ deg_slice, GcParams P, float* __restrict__ dx) {
+    const int l16 = threadIdx.x & 15;
+    const int grp = (threadIdx.x & 63) >> 4;
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool rok = row < n_atoms;
+    int deg = 0;
+    long long lrow = 0;
+    if (rok) find_bucket(deg_slice, row, deg, lrow);
+    const int* arow = deg > 0 ? P.adj[deg - 1] + lrow * deg : nullptr;
+    // position of this atom inside each neighbour's own list: lane m of the group probes entry m, a ballot finds it
+    int nbr[10];
+    unsigned pos[10];
+#pragma unroll
+    for (int n = 0; n < 10; ++n) {
+        int j = -1, hit = 0;
+        if (n < deg) {
+            j = min(max(arow[n], 0), n_atoms - 1);
+            int dj;
+            long long lj;
+            find_bucket(deg_slice, j, dj, lj);
+            if (l16 < dj) hit = P.adj[dj - 1][lj * dj + l16] == (int)row;
+        }
+        const unsigned long long b = __ballot(hit);
+        const unsigned m16 = (unsigned)(b >> (16 * grp)) & 0xFFFFu;
+        nbr[n] = j;
+        pos[n] = m16 ? (unsigned)__ffs(m16) : 0xFFu;       // 1-based position = the arg-max code of that neighbour
+    }
+    if (!rok) return;
+    for (int c = 4 * l16; c < f; c += 64) {
+        const unsigned a0 = *reinterpret_cast<const unsigned*>(arg + row * f + c);
+        const float4 g0 = *reinterpret_cast<const float4*>(dy + row * f + c);
+        float4 s;
+        s.x = (a0 & 0xFF) == 0 ? g0.x : 0.f;
+        s.y = ((a0 >> 8) & 0xFF) == 0 ? g0.y : 0.f;
+        s.z = ((a0 >> 16) & 0xFF) == 0 ? g0.z : 0.f;
+        s.w = (a0 >> 24) == 0 ? g0.w : 0.f;
+#pragma unroll
+        for (int n = 0; n < 10; ++n) {
+            if (n < deg) {
+                const long long j = nbr[n];
+                const unsigned a = *reinterpret_cast<const unsigned*>(arg + j * f + c);
+                const float4 g = *reinterpret_cast<const float4*>(dy + j * f + c);
+                const unsigned p = pos[n];
+                s.x += (a & 0xFF) == p ? g.x : 0.f;
+                s.y += ((a >> 8) & 0xFF) == p ? g.y : 0.f;
+                s.z += ((a >> 16) & 0xFF) == p ? g.z : 0.f;
+                s.w += (a >> 24) == p ? g.w : 0.f;
+            }
+        }
+        *reinterpret_cast<float4*>(dx + row * f + c) = s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ GraphGather2D
 // out[a][b][:] = x[mol_off[b] + a][:] if a < n_b else 0   (contiguous chunks of the degree-sorted atom tensor)
 __global__ void gather2d_fwd_kernel(const float* __restrict__ x, const int* __restrict__ mol_off, int a_max, int bsz,
@@ -561,38 +795,66 @@ static int fill_params(GcParams& P, const int32_t* const* adj, const float* cons
     return 0;
 }
 
-extern "C" int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t n_atoms, int f_in, int f_out,
+extern "C" size_t jova_graphconv_workspace_floats(int f_in, int f_out) {
+    const int kh = (f_in + 1) / 2, ncb = (f_out + 31) / 32;
+    return (size_t)21 * kh * ncb * 64;
+}
+
+extern "C" int jova_atoms_to_f32(const int64_t* atoms, int64_t n_atoms, int f, int ld, float* out, void* stream) {
+    JOVA_CHECK_ARG(atoms && out && n_atoms >= 0 && f >= 1 && ld >= f, "atoms_to_f32: bad argument");
+    if (n_atoms == 0) return JOVA_OK;
+    const long long total = n_atoms * ld;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(atoms_to_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const long long*)atoms,
+                       (long long)n_atoms, f, ld, out);
+    JOVA_CHECK_LAUNCH("atoms_to_f32");
+    return JOVA_OK;
+}
+
+extern "C" int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t ld_atoms, int64_t n_atoms, int f_in, int f_out,
                                   const int64_t* deg_slice, const int32_t* const* adj, const float* const* weight,
-                                  const float* const* bias, int relu, float* out, double* bn_stats, void* stream) {
+                                  const float* const* bias, int relu, float* out, double* bn_stats,
+                                  float* packed_ws, void* stream) {
     JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 31), "graphconv_fwd: n_atoms %lld out of range", (long long)n_atoms);
     JOVA_CHECK_ARG(f_in >= 1 && f_in <= 128, "graphconv_fwd: f_in %d not in [1,128]", f_in);
     JOVA_CHECK_ARG(f_out >= 1, "graphconv_fwd: f_out %d", f_out);
-    JOVA_CHECK_ARG(atoms && deg_slice && adj && weight && bias && out, "graphconv_fwd: null pointer");
+    JOVA_CHECK_ARG(ld_atoms >= f_in && ld_atoms < (1 << 20), "graphconv_fwd: ld_atoms %lld < f_in", (long long)ld_atoms);
+    JOVA_CHECK_ARG(atoms && deg_slice && adj && weight && bias && out && packed_ws, "graphconv_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     if (bn_stats) JOVA_CHECK_HIP(hipMemsetAsync(bn_stats, 0, sizeof(double) * 2 * f_out, s));
     if (n_atoms == 0) return JOVA_OK;
     GcParams P;
     fill_params(P, adj, weight, bias);
-    const int KS = ((f_in + 1) & ~1) | 1;
-    const size_t lds = sizeof(float) * 2 * TM * KS;
-    dim3 grid(cdiv(n_atoms, TM) + NB, cdiv(f_out, 64));
+    const int kh = (f_in + 1) / 2, ncb = (f_out + 31) / 32;
+    const long long wtotal = 21ll * kh * ncb * 64;
+    hipLaunchKernelGGL(graphconv_pack_kernel, dim3(cdiv(wtotal, 256)), dim3(256), 0, s, P, f_in, f_out, kh, ncb,
+                       packed_ws);
+    JOVA_CHECK_LAUNCH("graphconv_pack");
+    const int tiles = cdiv(n_atoms, TM);
+    const int group = tiles > 4096 ? cdiv(tiles, 2048) : 1;
+    dim3 grid(cdiv(tiles, group) + NB, cdiv(f_out, 64));
+    const size_t lds = sizeof(float) * 2 * TM * (2 * kh + 1);
     if (atoms_is_i64)
         hipLaunchKernelGGL(graphconv_fwd_kernel<long long>, grid, dim3(256), lds, s, (const long long*)atoms,
-                           (int)n_atoms, f_in, f_out, (const long long*)deg_slice, P, relu, out, bn_stats);
+                           (int)n_atoms, f_in, (int)ld_atoms, f_out, (const long long*)deg_slice, P, packed_ws, kh, ncb,
+                           relu, out, bn_stats, group);
     else
         hipLaunchKernelGGL(graphconv_fwd_kernel<float>, grid, dim3(256), lds, s, (const float*)atoms, (int)n_atoms,
-                           f_in, f_out, (const long long*)deg_slice, P, relu, out, bn_stats);
+                           f_in, (int)ld_atoms, f_out, (const long long*)deg_slice, P, packed_ws, kh, ncb, relu, out,
+                           bn_stats, group);
     JOVA_CHECK_LAUNCH("graphconv_fwd");
     return JOVA_OK;
 }
 
-extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t n_atoms, int f_in, int f_out,
-                                  const int64_t* deg_slice, const int32_t* const* adj, const float* const* weight,
-                                  const float* dy, const float* y_or_null, float* const* dweight, float* const* dbias,
-                                  float* dx_or_null, float* gbuf_or_null, const int* sym_flag, void* stream) {
+extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t ld_atoms, int64_t n_atoms, int f_in,
+                                  int f_out, const int64_t* deg_slice, const int32_t* const* adj,
+                                  const float* const* weight, const float* dy, const float* y_or_null,
+                                  float* const* dweight, float* const* dbias, float* dx_or_null, float* gbuf_or_null,
+                                  const int* sym_flag, void* stream) {
     JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 31), "graphconv_bwd: n_atoms out of range");
     JOVA_CHECK_ARG(f_in >= 1 && f_in <= 128, "graphconv_bwd: f_in %d not in [1,128]", f_in);
     JOVA_CHECK_ARG(f_out >= 1 && f_out <= 64, "graphconv_bwd: f_out %d not in [1,64]", f_out);
+    JOVA_CHECK_ARG(ld_atoms >= f_in && ld_atoms < (1 << 20), "graphconv_bwd: ld_atoms %lld < f_in", (long long)ld_atoms);
     JOVA_CHECK_ARG(atoms && deg_slice && adj && dy && dweight && dbias, "graphconv_bwd: null pointer");
     JOVA_CHECK_ARG(!dx_or_null || (gbuf_or_null && weight && !atoms_is_i64), "graphconv_bwd: dx needs gbuf, weights, f32 atoms");
     if (n_atoms == 0) return JOVA_OK;
@@ -606,18 +868,11 @@ extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t n
     const int tiles = cdiv(n_atoms, TM);
     const int group = tiles > 1024 ? cdiv(tiles, 768) : 1;
     dim3 grid(cdiv(tiles, group) + NB);
-    if (atoms_is_i64)
-        hipLaunchKernelGGL((graphconv_bwd_kernel<long long, false>), grid, dim3(256), lds, s, (const long long*)atoms,
-                           (int)n_atoms, f_in, f_out, (const long long*)deg_slice, P, dy, y_or_null, G, nullptr,
-                           nullptr, group);
-    else if (!dx_or_null)
-        hipLaunchKernelGGL((graphconv_bwd_kernel<float, false>), grid, dim3(256), lds, s, (const float*)atoms,
-                           (int)n_atoms, f_in, f_out, (const long long*)deg_slice, P, dy, y_or_null, G, nullptr,
-                           nullptr, group);
-    else
-        hipLaunchKernelGGL((graphconv_bwd_kernel<float, true>), grid, dim3(256), lds, s, (const float*)atoms,
-                           (int)n_atoms, f_in, f_out, (const long long*)deg_slice, P, dy, y_or_null, G, gbuf_or_null,
-                           dx_or_null, group);
+#define GC_BWD(T, DX, G_, D_) hipLaunchKernelGGL((graphconv_bwd_kernel<T, DX>), grid, dim3(256), lds, s, (const T*)atoms, \
+                                  (int)n_atoms, f_in, (int)ld_atoms, f_out, (const long long*)deg_slice, P, dy, y_or_null, G, G_, D_, group)
+    if (atoms_is_i64) GC_BWD(long long, false, nullptr, nullptr);
+    else if (!dx_or_null) GC_BWD(float, false, nullptr, nullptr);
+    else GC_BWD(float, true, gbuf_or_null, dx_or_null);
     JOVA_CHECK_LAUNCH("graphconv_bwd");
     if (dx_or_null) {
         hipLaunchKernelGGL(graphconv_bwd_dx_kernel, dim3(cdiv(n_atoms, 4)), dim3(256), 0, s, (int)n_atoms, f_in,
@@ -649,8 +904,12 @@ extern "C" int jova_graphpool_fwd(const float* x, int64_t n_atoms, int f, const 
     if (n_atoms == 0) return JOVA_OK;
     GcParams P;
     fill_params(P, adj, nullptr, nullptr);
-    hipLaunchKernelGGL(graphpool_fwd_kernel, dim3(cdiv(n_atoms, 4)), dim3(256), 0, (hipStream_t)stream, x,
-                       (int)n_atoms, f, (const long long*)deg_slice, P, out, argmax);
+    if ((f & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)out) | ((uintptr_t)argmax)) & 15) == 0)
+        hipLaunchKernelGGL(graphpool_fwd_v4_kernel, dim3(cdiv(n_atoms, 16)), dim3(256), 0, (hipStream_t)stream, x,
+                           (int)n_atoms, f, (const long long*)deg_slice, P, out, argmax);
+    else
+        hipLaunchKernelGGL(graphpool_fwd_kernel, dim3(cdiv(n_atoms, 4)), dim3(256), 0, (hipStream_t)stream, x,
+                           (int)n_atoms, f, (const long long*)deg_slice, P, out, argmax);
     JOVA_CHECK_LAUNCH("graphpool_fwd");
     return JOVA_OK;
 }
@@ -662,11 +921,17 @@ extern "C" int jova_graphpool_bwd(const float* dy, const uint8_t* argmax, int64_
     JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 31) && f >= 1, "graphpool_bwd: bad shape");
     if (n_atoms == 0) return JOVA_OK;
     hipStream_t s = (hipStream_t)stream;
-    (void)sym_flag_host_hint;
-    // the scatter path accumulates into dx; zeroing is harmless for the gather path (it overwrites)
-    JOVA_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)n_atoms * f, s));
     GcParams P;
     fill_params(P, adj, nullptr, nullptr);
+    // the caller may vouch for a symmetric adjacency (it read the flag once per batch): 16-lanes-per-row gather form
+    if (sym_flag_host_hint == 1 && (f & 3) == 0 && ((((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)argmax)) & 15) == 0) {
+        hipLaunchKernelGGL(graphpool_bwd_v4_kernel, dim3(cdiv(n_atoms, 16)), dim3(256), 0, s, dy, argmax,
+                           (int)n_atoms, f, (const long long*)deg_slice, P, dx);
+        JOVA_CHECK_LAUNCH("graphpool_bwd_v4");
+        return JOVA_OK;
+    }
+    // the scatter path accumulates into dx; zeroing is harmless for the gather path (it overwrites)
+    JOVA_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)n_atoms * f, s));
     hipLaunchKernelGGL(graphpool_bwd_kernel, dim3(cdiv(n_atoms, 4)), dim3(256), 0, s, dy, argmax, (int)n_atoms, f,
                        (const long long*)deg_slice, P, dx, sym_flag);
     JOVA_CHECK_LAUNCH("graphpool_bwd");

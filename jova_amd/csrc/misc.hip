@@ -61,9 +61,9 @@ __global__ void viewpool_fwd_kernel(const float* __restrict__ x, const int* __re
     const int c = (int)(t % l);
     const int v = (int)((t / l) % n_views);
     const int b = (int)(t / ((long long)l * n_views));
-    float s = 0.f;
-    for (int sgm = seg_off[v]; sgm < seg_off[v + 1]; ++sgm) s += x[((long long)sgm * bsz + b) * l + c];
-    out[t] = s;
+    double s = 0.0;      // fp64: the BatchNorm that follows subtracts a batch mean much larger than the spread
+    for (int sgm = seg_off[v]; sgm < seg_off[v + 1]; ++sgm) s += (double)x[((long long)sgm * bsz + b) * l + c];
+    out[t] = (float)s;
 }
 
 __global__ void viewpool_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ seg_off, int n_views,

@@ -20,25 +20,22 @@ colreduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, cons
     if (col < c) {
         float mu = 0.f, rs = 0.f;
         if (MODE == 1) { mu = mean_rstd[col]; rs = mean_rstd[c + col]; }
-        float f0 = 0.f, f1 = 0.f;
-        int cnt = 0;
+        // fp64 accumulation element by element: sum(x^2)/n - mean^2 cancels catastrophically in fp32 when
+        // |mean| >> std (e.g. the 279-segment view sums that feed JointAttention's BatchNorm)
         for (long long r = r0 + ty; r < r1; r += 4) {
             if (MODE == 0) {
-                const float v = x[r * ld + col];
-                f0 += v;
-                f1 += v * v;
+                const double v = (double)x[r * ld + col];
+                s0 += v;
+                s1 += v * v;
             } else if (MODE == 1) {
                 float g = dy[r * ld + col];
                 if (y && !(y[r * ld + col] > 0.f)) g = 0.f;
-                f0 += g;
-                f1 += g * ((x[r * ld + col] - mu) * rs);
+                s0 += (double)g;
+                s1 += (double)g * (double)((x[r * ld + col] - mu) * rs);
             } else {
-                f0 += x[r * ld + col];
+                s0 += (double)x[r * ld + col];
             }
-            if (++cnt == 64) { s0 += f0; s1 += f1; f0 = f1 = 0.f; cnt = 0; }   // bound the fp32 run length
         }
-        s0 += f0;
-        s1 += f1;
     }
     red[0][ty][tx] = s0;
     red[1][ty][tx] = s1;

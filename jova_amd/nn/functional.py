@@ -74,6 +74,26 @@ class Topology(object):
         self.sym_flag = torch.empty(1, dtype=torch.int32, device=dev)
         call("jova_adj_symmetry", self.n_atoms, P(self.deg_slice), self.adj_ptrs, P(self.sym_flag), stream())
         self._mol_off = None
+        self._atoms_f32 = None
+        self._sym_host = None
+
+    def atoms_f32(self, atoms):
+        """fp32 copy of the batch's int64 atom features, rows zero-padded to a multiple of 4 floats (made once)."""
+        key = (atoms.data_ptr(), tuple(atoms.shape))
+        if self._atoms_f32 is None or self._atoms_f32[0] != key:
+            n, f = atoms.shape
+            ld = (f + 3) // 4 * 4
+            out = torch.empty((n, ld), dtype=_F32, device=atoms.device)
+            call("jova_atoms_to_f32", P(atoms), n, f, ld, P(out), stream())
+            self._atoms_f32 = (key, out, atoms)      # keeps `atoms` alive so the pointer key stays unique
+        return self._atoms_f32[1]
+
+    @property
+    def symmetric(self):
+        """Host copy of the symmetry flag (one device->host read per batch, cached)."""
+        if self._sym_host is None:
+            self._sym_host = bool(self.sym_flag.item())
+        return self._sym_host
 
     @property
     def mol_off(self):
@@ -100,7 +120,11 @@ def topology_of(input_data):
 
 # ------------------------------------------------------------------------------------------------------ graph ops
 class GraphConvFunction(torch.autograd.Function):
-    """GraphConvLayer.forward (jova/nn/layers.py:295-347) as one launch; backward as two."""
+    """GraphConvLayer.forward (jova/nn/layers.py:295-347): weight re-pack + one launch; backward two launches.
+
+    int64 atom features (layer 1) are converted once per batch to fp32 rows padded to a multiple of 4 floats
+    (exact: they are small integers) and cached on the batch topology; the kernels then read whole rows with
+    16-byte loads."""
 
     @staticmethod
     def forward(ctx, atoms, topo, relu, stats, *wb):
@@ -111,26 +135,27 @@ class GraphConvFunction(torch.autograd.Function):
             raise RuntimeError("GraphConvLayer: atom features must be int64 or float32, got %s" % atoms.dtype)
         n, f_in = atoms.shape
         f_out = weights[0].shape[0]
-        out = _empty((n, f_out), atoms)
-        call("jova_graphconv_fwd", P(atoms), int(is_i64), n, f_in, f_out, P(topo.deg_slice), topo.adj_ptrs,
-             ptr_array(weights), ptr_array(biases), int(relu), P(out), P(stats), stream())
-        ctx.topo, ctx.relu, ctx.is_i64, ctx.params = topo, relu, is_i64, wb
-        ctx.save_for_backward(atoms, out)
+        xf, ld = (topo.atoms_f32(atoms), (f_in + 3) // 4 * 4) if is_i64 else (atoms, f_in)
+        out = _empty((n, f_out), xf)
+        ws = _empty((int(_lib.lib().jova_graphconv_workspace_floats(f_in, f_out)),), weights[0])
+        call("jova_graphconv_fwd", P(xf), 0, ld, n, f_in, f_out, P(topo.deg_slice), topo.adj_ptrs,
+             ptr_array(weights), ptr_array(biases), int(relu), P(out), P(stats), P(ws), stream())
+        ctx.topo, ctx.relu, ctx.is_i64, ctx.params, ctx.dims = topo, relu, is_i64, wb, (n, f_in, f_out, ld)
+        ctx.save_for_backward(xf, out)
         ctx.weights = weights
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        atoms, out = ctx.saved_tensors
+        xf, out = ctx.saved_tensors
         topo = ctx.topo
         dy = _c(dy)
-        n, f_in = atoms.shape
-        f_out = out.shape[1]
+        n, f_in, f_out, ld = ctx.dims
         sink = _GradSink(ctx.params)
         need_dx = (not ctx.is_i64) and ctx.needs_input_grad[0]
         dx = _empty((n, f_in), out) if need_dx else None
         gbuf = _empty((n, f_in), out) if need_dx else None
-        call("jova_graphconv_bwd", P(atoms), int(ctx.is_i64), n, f_in, f_out, P(topo.deg_slice), topo.adj_ptrs,
+        call("jova_graphconv_bwd", P(xf), 0, ld, n, f_in, f_out, P(topo.deg_slice), topo.adj_ptrs,
              ptr_array(ctx.weights), P(dy), P(out) if ctx.relu else None, ptr_array(sink.targets[:21]),
              ptr_array(sink.targets[21:]), P(dx), P(gbuf), P(topo.sym_flag), stream())
         return (dx, None, None, None) + tuple(sink.returns)
@@ -157,8 +182,8 @@ class GraphPoolFunction(torch.autograd.Function):
         dy = _c(dy)
         n, f = dy.shape
         dx = _empty((n, f), dy)
-        call("jova_graphpool_bwd", P(dy), P(arg), n, f, P(topo.deg_slice), topo.adj_ptrs, P(dx), P(topo.sym_flag), 0,
-             stream())
+        call("jova_graphpool_bwd", P(dy), P(arg), n, f, P(topo.deg_slice), topo.adj_ptrs, P(dx), P(topo.sym_flag),
+             int(topo.symmetric), stream())
         return dx, None
 
 
@@ -600,6 +625,11 @@ class MSELossFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, outputs, weights, target):
+        if not (outputs.dtype == weights.dtype == target.dtype == _F32):
+            raise TypeError("MSELossFunction takes float32 outputs, weights and target, got %s/%s/%s"
+                            % (outputs.dtype, weights.dtype, target.dtype))
+        if not (outputs.shape == weights.shape == target.shape):
+            raise ValueError("MSELossFunction: outputs, weights and target must have one shape")
         o, w, y = _c(outputs), _c(weights), _c(target)
         loss = _empty((), o)
         dout = torch.empty_like(o)
