@@ -8,6 +8,7 @@
 // and the whole layer is a single launch; deg_slice is read on the device (no host sync).
 #include "common.h"
 #include "jova_hip.h"
+#include <stdlib.h>
 
 #define TM 64
 #define NB 11
@@ -274,6 +275,317 @@ graphconv_fwd_kernel(const TIn* __restrict__ x, int n_atoms, int f_in, int ldx, 
         }
     }
     if (stats) {      // per-column sum / sum of squares for the BatchNorm that follows (fp64 accumulators)
+        s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (lane < 32 && colok) {
+            atomicAdd(&stats[col], s);
+            atomicAdd(&stats[f_out + col], q);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward, LDS-DMA form
+// The fast form of the forward (fp32 rows of 64 or 80 floats, 16-byte aligned).  Nothing is staged through registers:
+//   * gather: every row a tile needs (the 32 atoms' own rows and their neighbour rows) is copied HBM -> LDS by
+//     global_load_lds_dwordx4, 16 lanes per 256-byte row, all rows of the tile in flight at once, no VGPRs held.
+//     Rows land as they are in memory: plane p (0 = own rows, 1.. = neighbours), atom r -> slot s = 32 p + r; the
+//     16-byte chunk c of a row sits at chunk position c ^ (s & 15), chosen on the SOURCE address (the LDS side of the
+//     DMA is lane-linear), so the fragment reads below are bank-conflict free.  Rows of 80 floats keep floats 64..79
+//     in a second image [slot][16] with chunk position c ^ ((s >> 2) & 3).
+//   * MFMA: a wave owns 32 atoms x 32 output columns (2 waves per workgroup).  The k order of the contraction is
+//     permuted so that lane (i, h) reads ONE ds_read_b128 per four MFMAs: group g, step s uses features 8g + 4h + s.
+//     The neighbour sum is formed on the fly while reading the fragments, the weights of the workgroup's degree
+//     stay in registers (re-packed in the same k order) for all of its tiles.
+//   * pipeline: the LDS holds NPL planes.  A tile of degree d needs 1 + d of them; when two tiles fit (d = 1 with 4
+//     planes, d <= 3 with 8) the rows of tile t+1 are in flight while tile t is in the MFMA, and the stores of tile
+//     t-1 are issued behind them, so a wave waits for memory only at the top of a tile for requests that have had a
+//     whole MFMA phase to complete.  The adjacency indices are always fetched one tile further ahead.  Otherwise
+//     the next tile's rows are issued right after the MFMA phase, in front of this tile's stores.
+//   * degrees > NPL - 1 take several gather rounds; the partial neighbour sums go through the MFMA one after another
+//     (the product is linear in the sum).  High degrees are dispatched first so their longer tiles are not the tail.
+#define GT 32
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ bool locate_tiles_desc(const long long* __restrict__ deg_slice, int blk, int group,
+                                                  int& deg, long long& bstart, int& bsize, int& tile0, int& ntile) {
+    for (int d = NB - 1; d >= 0; --d) {
+        const int size = (int)deg_slice[2 * d + 1];
+        const int tiles = (size + GT - 1) / GT;
+        const int groups = (tiles + group - 1) / group;
+        if (blk < groups) {
+            deg = d;
+            bstart = deg_slice[2 * d];
+            bsize = size;
+            tile0 = blk * group;
+            ntile = min(group, tiles - tile0);
+            return true;
+        }
+        blk -= groups;
+    }
+    return false;
+}
+
+// weights -> B fragments in the permuted k order:
+//   Wq[w][cb][g][lane][s] = W_w[32 cb + (lane & 31)][8 g + 4 (lane >> 5) + s]   (zero padded)
+__global__ void graphconv_pack_dma_kernel(GcParams P, int f_in, int f_out, int kg, int ncb, float* __restrict__ wq) {
+    const long long total = 21ll * ncb * kg * 256;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int s = (int)(e & 3), lane = (int)((e >> 2) & 63);
+        long long q = e >> 8;
+        const int g = (int)(q % kg);
+        q /= kg;
+        const int cb = (int)(q % ncb), w = (int)(q / ncb);
+        const int col = 32 * cb + (lane & 31), k = 8 * g + 4 * (lane >> 5) + s;
+        wq[e] = (col < f_out && k < f_in) ? P.w[w][(long long)col * f_in + k] : 0.f;
+    }
+}
+
+// Where the planes live.  The LDS is two separate static arrays of NPL/2 planes each (main image, then tail image):
+// while tile t is read from one array the DMA of tile t+1 writes the other, and because they are distinct objects the
+// compiler does not put a vmcnt(0) in front of the fragment reads (it does when DMA and reads share one array).
+template <int KG, int NPL>
+struct HalfBuf {                                                 // planes 0 .. NPL/2-1 of ONE array
+    float* base;
+    __device__ __forceinline__ float* main(int lp) const { return base + lp * (GT * 64); }
+    __device__ __forceinline__ float* tail(int lp) const { return base + (NPL / 2) * (GT * 64) + lp * (GT * 16); }
+};
+template <int KG, int NPL>
+struct FullBuf {                                                 // planes 0 .. NPL-1 across both arrays
+    float* b0;
+    float* b1;
+    __device__ __forceinline__ float* main(int pp) const {
+        return (pp < NPL / 2 ? b0 : b1) + (pp % (NPL / 2)) * (GT * 64);
+    }
+    __device__ __forceinline__ float* tail(int pp) const {
+        return (pp < NPL / 2 ? b0 : b1) + (NPL / 2) * (GT * 64) + (pp % (NPL / 2)) * (GT * 16);
+    }
+};
+
+// Row numbers of the planes [p_begin, p_end) of a tile (plane 0 = own rows, plane p >= 1 = neighbour nb0 + p - 1),
+// in the two lane -> slot maps the DMA uses (main image: 16 lanes per slot; tail image: 4 lanes per slot).
+template <int KG, int NPL>
+struct RowIdx {
+    int main[NPL * 4];
+    int tail[KG > 8 ? NPL : 1];
+    // (no arithmetic on the loaded values here: while a DMA is in flight a use of an ordinary load's result makes
+    // the compiler wait for vmcnt(0), which would drain the DMA too; they are clamped at issue time)
+    __device__ __forceinline__ void load(const int* __restrict__ adj_d, int deg, int lrow0, long long row0, int rows,
+                                         int nb0, int p_begin, int p_end, int tid) {
+        const int sub = tid >> 4;
+#pragma unroll
+        for (int it = 0; it < NPL * 4; ++it) {
+            const int p = it >> 2;
+            const int r = (it & 3) * 8 + sub;
+            const int rc = r < rows ? r : rows - 1;
+            main[it] = 0;
+            if (p >= p_begin && p < p_end) {
+                if (p == 0) main[it] = (int)(row0 + rc);
+                else main[it] = adj_d[(long long)(lrow0 + rc) * deg + nb0 + p - 1];
+            }
+        }
+        if (KG > 8) {
+            const int r = tid >> 2;
+            const int rc = r < rows ? r : rows - 1;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                tail[p] = 0;
+                if (p >= p_begin && p < p_end) {
+                    if (p == 0) tail[p] = (int)(row0 + rc);
+                    else tail[p] = adj_d[(long long)(lrow0 + rc) * deg + nb0 + p - 1];
+                }
+            }
+        }
+    }
+    // issues the DMA of those planes into the planes of `buf`
+    template <typename Buf>
+    __device__ __forceinline__ void issue(const float* __restrict__ x, int n_atoms, int ldx, int p_begin, int p_end,
+                                          const Buf& buf, int tid) const {
+        const int wave = tid >> 6;
+        {
+            const int sub = tid >> 4, pos = tid & 15;
+#pragma unroll
+            for (int it = 0; it < NPL * 4; ++it) {
+                const int p = it >> 2;
+                const int sw = ((it & 1) * 8 + sub) & 15;        // slot & 15
+                if (p >= p_begin && p < p_end)
+                    glds16(x + (long long)min(max(main[it], 0), n_atoms - 1) * ldx + ((pos ^ sw) << 2),
+                           buf.main(p) + ((it & 3) * 8 + wave * 4) * 64);
+            }
+        }
+        if (KG > 8) {
+            const int r = tid >> 2, pos = tid & 3;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                if (p >= p_begin && p < p_end)
+                    glds16(x + (long long)min(max(tail[p], 0), n_atoms - 1) * ldx + 64 + ((pos ^ ((r >> 2) & 3)) << 2),
+                           buf.tail(p) + (wave * 16) * 16);
+            }
+        }
+    }
+};
+
+template <int G, typename Buf>
+__device__ __forceinline__ float4 frag_dma(const Buf& buf, int p, int r, int h) {
+    if (G < 8) return *reinterpret_cast<const float4*>(buf.main(p) + r * 64 + (((2 * G + h) ^ (r & 15)) << 2));
+    return *reinterpret_cast<const float4*>(buf.tail(p) + r * 16 + (((2 * (G - 8) + h) ^ ((r >> 2) & 3)) << 2));
+}
+
+// acc += (sum of planes p0 .. p0+cnt-1)[32 atoms x 8 KG] * b   in the permuted k order
+template <int KG, int G>
+struct DmaPass {
+    template <typename Buf>
+    static __device__ __forceinline__ void run(const Buf& buf, int p0, int cnt, int r, int h, const float4* b,
+                                               f32x16& acc) {
+        float4 a = frag_dma<G>(buf, p0, r, h);
+        for (int n = 1; n < cnt; ++n) {
+            const float4 v = frag_dma<G>(buf, p0 + n, r, h);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[G].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[G].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[G].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[G].w, acc, 0, 0, 0);
+        DmaPass<KG, G + 1>::run(buf, p0, cnt, r, h, b, acc);
+    }
+};
+template <int KG>
+struct DmaPass<KG, KG> {
+    template <typename Buf>
+    static __device__ __forceinline__ void run(const Buf&, int, int, int, int, const float4*, f32x16&) {}
+};
+
+template <int KG, int NPL>
+__global__ void __launch_bounds__(128, (NPL <= 4 ? 2 : 1))
+graphconv_fwd_dma_kernel(const float* __restrict__ x, int n_atoms, int ldx, int f_out,
+                         const long long* __restrict__ deg_slice, GcParams P, const float* __restrict__ wq, int ncb,
+                         int relu, float* __restrict__ out, double* __restrict__ stats, int group) {
+    constexpr int HALF = (NPL / 2) * GT * (KG > 8 ? 80 : 64);
+    __shared__ __attribute__((aligned(16))) float lds0[HALF];
+    __shared__ __attribute__((aligned(16))) float lds1[HALF];
+    int deg, tile0, ntile, bsize;
+    long long bstart;
+    if (!locate_tiles_desc(deg_slice, blockIdx.x, group, deg, bstart, bsize, tile0, ntile)) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int cb = blockIdx.y * 2 + wave;
+    const int col = 32 * cb + i;
+    const bool colok = col < f_out && cb < ncb;
+    const int cbc = cb < ncb ? cb : ncb - 1;
+    const int w_rel = deg > 0 ? 2 * (deg - 1) : 20, w_self = deg == 0 ? 20 : 2 * (deg - 1) + 1;
+    const int* adj_d = deg > 0 ? P.adj[deg - 1] : nullptr;
+    const int cnt0 = min(deg, NPL - 1);          // neighbour planes of the first round
+    const int ppt = cnt0 + 1;                    // planes a tile occupies
+    const bool db = 2 * ppt <= NPL;              // a tile fits one array: software pipeline over the two
+    const HalfBuf<KG, NPL> half0{lds0}, half1{lds1};
+    const FullBuf<KG, NPL> full{lds0, lds1};
+
+    RowIdx<KG, NPL> idx;
+    idx.load(adj_d, deg, tile0 * GT, bstart + (long long)tile0 * GT, min(GT, bsize - tile0 * GT), 0, 0, ppt, tid);
+    float4 bself[KG], brel[KG];
+    {
+        const float4* ws = reinterpret_cast<const float4*>(wq) + (((long long)w_self * ncb + cbc) * KG) * 64 + lane;
+        const float4* wr = reinterpret_cast<const float4*>(wq) + (((long long)w_rel * ncb + cbc) * KG) * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            bself[g] = ws[g * 64];
+            brel[g] = wr[g * 64];
+        }
+    }
+    float bias = 0.f;
+    if (colok) {
+        bias = P.b[w_self][col];
+        if (deg > 0) bias += P.b[w_rel][col];
+    }
+    double s = 0.0, q = 0.0;
+    if (db) idx.issue(x, n_atoms, ldx, 0, ppt, half0, tid);
+    else idx.issue(x, n_atoms, ldx, 0, ppt, full, tid);
+    if (ntile > 1)
+        idx.load(adj_d, deg, (tile0 + 1) * GT, bstart + (long long)(tile0 + 1) * GT, min(GT, bsize - (tile0 + 1) * GT),
+                 0, 0, ppt, tid);
+
+    auto store_tile = [&](const f32x16& a, long long row0, int rows) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma32_row(r, lane);
+            float v = a[r] + bias;
+            if (relu) v = fmaxf(v, 0.f);
+            if (row < rows && colok) {
+                out[(row0 + row) * f_out + col] = v;
+                s += (double)v;
+                q += (double)v * (double)v;
+            }
+        }
+    };
+    auto prefetch_idx = [&](int t) {             // adjacency indices of tile t (if the workgroup has one)
+        if (t < ntile) {
+            const int l = (tile0 + t) * GT;
+            idx.load(adj_d, deg, l, bstart + l, min(GT, bsize - l), 0, 0, ppt, tid);
+        }
+    };
+
+    if (db) {
+        f32x16 acc, prev;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) prev[r] = 0.f;
+        long long prev_row0 = 0;
+        int prev_rows = 0;
+        auto step = [&](const HalfBuf<KG, NPL>& cur, const HalfBuf<KG, NPL>& nxt, int t) {
+            const int lrow0 = (tile0 + t) * GT;
+            // rows of tile t landed (and the prefetched indices, and the stores of tile t-2: all issued a whole MFMA
+            // phase ago); every wave is past its reads of tile t-1.  The wait is explicit: with the two arrays being
+            // distinct objects the barrier alone does not drain the DMA.
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            __syncthreads();
+            if (t + 1 < ntile) idx.issue(x, n_atoms, ldx, 0, ppt, nxt, tid);
+            prefetch_idx(t + 2);
+            if (t > 0) store_tile(prev, prev_row0, prev_rows);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            DmaPass<KG, 0>::run(cur, 0, 1, i, h, bself, acc);
+            if (cnt0 > 0) DmaPass<KG, 0>::run(cur, 1, cnt0, i, h, brel, acc);
+            prev = acc;
+            prev_row0 = bstart + lrow0;
+            prev_rows = min(GT, bsize - lrow0);
+        };
+        for (int t = 0; t < ntile; t += 2) {
+            step(half0, half1, t);
+            if (t + 1 < ntile) step(half1, half0, t + 1);
+        }
+        store_tile(prev, prev_row0, prev_rows);
+    } else {
+        for (int t = 0; t < ntile; ++t) {
+            const int lrow0 = (tile0 + t) * GT;
+            const int rows = min(GT, bsize - lrow0);
+            const long long row0 = bstart + lrow0;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): rows of tile t (first round) landed
+            __syncthreads();
+            DmaPass<KG, 0>::run(full, 0, 1, i, h, bself, acc);
+            if (cnt0 > 0) DmaPass<KG, 0>::run(full, 1, cnt0, i, h, brel, acc);
+            for (int nb0 = NPL - 1; nb0 < deg; nb0 += NPL - 1) {  // further rounds of a high-degree tile
+                const int cnt = min(NPL - 1, deg - nb0);
+                RowIdx<KG, NPL> more;
+                more.load(adj_d, deg, lrow0, row0, rows, nb0, 1, cnt + 1, tid);
+                __syncthreads();
+                more.issue(x, n_atoms, ldx, 1, cnt + 1, full, tid);
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                __syncthreads();
+                DmaPass<KG, 0>::run(full, 1, cnt, i, h, brel, acc);
+            }
+            __syncthreads();                     // this tile's fragment reads are done
+            if (t + 1 < ntile) idx.issue(x, n_atoms, ldx, 0, ppt, full, tid);
+            prefetch_idx(t + 2);
+            store_tile(acc, row0, rows);
+        }
+    }
+    if (stats) {
         s += __shfl_xor(s, 32, 64);
         q += __shfl_xor(q, 32, 64);
         if (lane < 32 && colok) {
@@ -796,8 +1108,9 @@ static int fill_params(GcParams& P, const int32_t* const* adj, const float* cons
 }
 
 extern "C" size_t jova_graphconv_workspace_floats(int f_in, int f_out) {
-    const int kh = (f_in + 1) / 2, ncb = (f_out + 31) / 32;
-    return (size_t)21 * kh * ncb * 64;
+    const int kh = (f_in + 1) / 2, ncb = (f_out + 31) / 32, kg = (f_in + 7) / 8;
+    const size_t a = (size_t)21 * kh * ncb * 64, b = (size_t)21 * ncb * kg * 256;
+    return a > b ? a : b;
 }
 
 extern "C" int jova_atoms_to_f32(const int64_t* atoms, int64_t n_atoms, int f, int ld, float* out, void* stream) {
@@ -826,6 +1139,37 @@ extern "C" int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t l
     GcParams P;
     fill_params(P, adj, weight, bias);
     const int kh = (f_in + 1) / 2, ncb = (f_out + 31) / 32;
+    const int kg = (f_in + 7) / 8;
+    // fast form: fp32 rows of 64 or 80 floats read whole by 16-byte LDS-DMA; columns f_in .. 8 kg - 1 of a row are
+    // multiplied by zero weights, so they must exist (ld >= 8 kg) and hold finite values (the fp32 copy of int64
+    // atoms is zero padded)
+    if (!atoms_is_i64 && (kg == 8 || kg == 10) && ld_atoms >= 8 * kg && (ld_atoms & 3) == 0 &&
+        (((uintptr_t)atoms) & 15) == 0 && !getenv("JOVA_GRAPHCONV_NO_DMA")) {
+        const long long qtotal = 21ll * ncb * kg * 256;
+        hipLaunchKernelGGL(graphconv_pack_dma_kernel, dim3(cdiv(qtotal, 256)), dim3(256), 0, s, P, f_in, f_out, kg, ncb,
+                           packed_ws);
+        JOVA_CHECK_LAUNCH("graphconv_pack_dma");
+        const int tiles = cdiv(n_atoms, GT);
+        const int group = tiles > 2048 ? 4 : (tiles > 512 ? 2 : 1);
+        dim3 grid(cdiv(tiles, group) + NB, cdiv(f_out, 64));
+        static int npl_env = -1;
+        if (npl_env < 0) {
+            const char* e = getenv("JOVA_GRAPHCONV_PLANES");
+            npl_env = e ? atoi(e) : 0;
+        }
+        const int npl = npl_env == 8 ? 8 : 4;
+#define GC_DMA(KG_, NPL_)                                                                                              \
+    hipLaunchKernelGGL((graphconv_fwd_dma_kernel<KG_, NPL_>), grid, dim3(128), 0, s, (const float*)atoms,              \
+                       (int)n_atoms, (int)ld_atoms, f_out, (const long long*)deg_slice, P, packed_ws, ncb, relu, out,  \
+                       bn_stats, group)
+        if (kg == 8 && npl == 4) GC_DMA(8, 4);
+        else if (kg == 8) GC_DMA(8, 8);
+        else if (npl == 4) GC_DMA(10, 4);
+        else GC_DMA(10, 8);
+#undef GC_DMA
+        JOVA_CHECK_LAUNCH("graphconv_fwd_dma");
+        return JOVA_OK;
+    }
     const long long wtotal = 21ll * kh * ncb * 64;
     hipLaunchKernelGGL(graphconv_pack_kernel, dim3(cdiv(wtotal, 256)), dim3(256), 0, s, P, f_in, f_out, kh, ncb,
                        packed_ws);

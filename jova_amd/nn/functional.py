@@ -30,6 +30,12 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _atoms_ld(f):
+    """Row stride (floats) of the fp32 copy of int64 atom features: whole 64-byte pieces, so the graph-conv kernels
+    can copy rows HBM -> LDS in 16-byte chunks without reading past a row."""
+    return (f + 15) // 16 * 16
+
+
 class _GradSink(object):
     """Where a parameter's gradient is accumulated (see module docstring)."""
 
@@ -78,11 +84,11 @@ class Topology(object):
         self._sym_host = None
 
     def atoms_f32(self, atoms):
-        """fp32 copy of the batch's int64 atom features, rows zero-padded to a multiple of 4 floats (made once)."""
+        """fp32 copy of the batch's int64 atom features, rows zero-padded to a multiple of 16 floats (made once)."""
         key = (atoms.data_ptr(), tuple(atoms.shape))
         if self._atoms_f32 is None or self._atoms_f32[0] != key:
             n, f = atoms.shape
-            ld = (f + 3) // 4 * 4
+            ld = _atoms_ld(f)
             out = torch.empty((n, ld), dtype=_F32, device=atoms.device)
             call("jova_atoms_to_f32", P(atoms), n, f, ld, P(out), stream())
             self._atoms_f32 = (key, out, atoms)      # keeps `atoms` alive so the pointer key stays unique
@@ -135,7 +141,7 @@ class GraphConvFunction(torch.autograd.Function):
             raise RuntimeError("GraphConvLayer: atom features must be int64 or float32, got %s" % atoms.dtype)
         n, f_in = atoms.shape
         f_out = weights[0].shape[0]
-        xf, ld = (topo.atoms_f32(atoms), (f_in + 3) // 4 * 4) if is_i64 else (atoms, f_in)
+        xf, ld = (topo.atoms_f32(atoms), _atoms_ld(f_in)) if is_i64 else (atoms, f_in)
         out = _empty((n, f_out), xf)
         ws = _empty((int(_lib.lib().jova_graphconv_workspace_floats(f_in, f_out)),), weights[0])
         call("jova_graphconv_fwd", P(xf), 0, ld, n, f_in, f_out, P(topo.deg_slice), topo.adj_ptrs,

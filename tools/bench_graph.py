@@ -1,6 +1,6 @@
 """Graph-kernel micro-benchmark on the config-4 batch (dev tool; GPU box only)."""
 import sys, json
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
 import bench
 dev = torch.device('cuda:0')
