@@ -12,12 +12,19 @@
 // prefetch of the next k-tile under the current tile's 64 MFMAs, several workgroups per CU for latency hiding.
 #include "common.h"
 #include "jova_hip.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
 #define BK 32
 #define LDS_KC (BK + 1)      // [row][k] image, odd stride: conflict-free ds_read_b32 down a column
 #define LDS_RC (BM + 4)      // [k][row] image, 16-byte aligned rows
+#ifndef GEMM_WGS
+#define GEMM_WGS 3           // workgroups per CU the register budget is held to
+#endif
+#ifndef GEMM_ABL
+#define GEMM_ABL 0           // dev-only ablation bits (tools/scratch/gemm_lab.hip); 0 in the product
+#endif
 
 struct GemmArgs {
     const float* A;
@@ -120,7 +127,7 @@ __device__ __forceinline__ float frag(const float* __restrict__ S, int row, int 
 }
 
 template <bool A_KC, bool B_KC, bool VA, bool VB>
-__global__ void __launch_bounds__(256, 3)      // 3 workgroups per CU: <= 168 VGPR+AGPR
+__global__ void __launch_bounds__(256, GEMM_WGS)      // 3 workgroups per CU: <= 168 VGPR+AGPR
 gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[A_KC ? BM * LDS_KC : BK * LDS_RC];
     __shared__ __attribute__((aligned(16))) float Bs[B_KC ? BN * LDS_KC : BK * LDS_RC];
@@ -166,11 +173,13 @@ gemm_f32_kernel(GemmArgs g) {
         load_operand<B_KC, VB>(B, g.sbn, g.sbk, n0, g.N, kbeg, kend, tid, vb);
     }
     for (int t = 0; t < nt; ++t) {
-        __syncthreads();
-        store_operand<A_KC>(As, tid, va);
-        store_operand<B_KC>(Bs, tid, vb);
-        __syncthreads();
-        if (t + 1 < nt) {
+        if (!(GEMM_ABL & 4) || t == 0) {
+            __syncthreads();
+            store_operand<A_KC>(As, tid, va);
+            store_operand<B_KC>(Bs, tid, vb);
+            __syncthreads();
+        }
+        if (t + 1 < nt && !(GEMM_ABL & 1)) {
             load_operand<A_KC, VA>(A, g.sam, g.sak, m0, g.M, kbeg + (t + 1) * BK, kend, tid, va);
             load_operand<B_KC, VB>(B, g.sbn, g.sbk, n0, g.N, kbeg + (t + 1) * BK, kend, tid, vb);
         }
@@ -221,10 +230,321 @@ gemm_f32_kernel(GemmArgs g) {
                     const int m = mbase + mfma32_row(r, lane);
                     float v = g.alpha * acc[a][b][r] + bias + rv[r];
                     if (g.relu) v = fmaxf(v, 0.f);
-                    if (m < g.M && nok) C[(long long)m * g.ldc + n] = v;
+                    if (m < g.M && nok && (!(GEMM_ABL & 2) || v == 1.2345e-30f)) C[(long long)m * g.ldc + n] = v;
                 }
             }
         }
+}
+
+// ------------------------------------------------------------------------------------------------ aligned fast form
+// For the big contractions of the joint-attention block (M, N multiples of 128, K of 32, 16-byte aligned operands, no
+// batch): same 128x128x32 tiling and the same exact-fp32 MFMA, but
+//   * operands go HBM/L2 -> LDS by global_load_lds_dwordx4 (no VGPR staging, no ds_write, no select VALU), into two
+//     LDS stages that are two distinct arrays (one barrier per k-tile; the DMA of k-tile t+1 flies under the MFMAs of t);
+//   * a K-contiguous operand lands as [row][32 k] with the 16-byte chunk c of row r at chunk position c ^ ((r>>1)&7)
+//     (chosen on the SOURCE address; the LDS side of the DMA is lane-linear) and is read back with ONE conflict-free
+//     ds_read_b128 per four MFMAs: the k order of the contraction is permuted (group g, step s uses k = 8g + 4h + s
+//     for lane half h), identically for A and B, which only changes the fp32 summation order;
+//   * a row-contiguous operand lands as [k][128 rows]; for A the wave's two 32-row tiles interleave rows (tile a owns
+//     rows 2i + a) so both come from one ds_read_b64 (the permutation is undone in the epilogue for free);
+//   * the grid is persistent: a workgroup walks its work items (output tile x K split) as ONE flat stream of k-tiles,
+//     so the first k-tile of the next item is already in flight during the epilogue of the current one.
+#ifndef FBK
+#define FBK 16               // k-tile depth of the fast form
+#endif
+#ifndef FNST
+#define FNST 3               // LDS stages (each its own array)
+#endif
+#ifndef FWGS
+#define FWGS 3               // persistent workgroups per CU
+#endif
+#define FCH (FBK / 4)                    // 16-byte chunks per K-contiguous row
+#define FRP (64 / FCH)                   // rows per 1 KiB DMA piece of a K-contiguous operand
+#define FPCS (128 * FBK / 256 / 4)       // DMA pieces per wave per operand per k-tile
+#define STAGE_FLOATS (2 * 128 * FBK)     // A tile then B tile
+
+// 16 bytes per lane HBM/L2 -> LDS (lane l lands at l_base + 16 l).  Issued as inline asm on purpose: hipcc's
+// waitcnt pass treats the builtin as an LDS write that may alias every later ds_read and, once the vmcnt waits are
+// conditional (multi-stage pipeline), drains vmcnt(0) between the DMA issue and the fragment reads of the OTHER stage.
+// Completion is tracked by hand (the s_waitcnt vmcnt in step()); the "memory" clobber keeps LDS reads on their side.
+__device__ __forceinline__ void dma16(const float* g, unsigned lds) {     // lds: wave-uniform LDS byte address
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_addr(const float* p) {            // LDS byte address of a __shared__ object
+    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) float*)p);
+}
+__device__ __forceinline__ int fswz(int row) { return FBK == 32 ? (row >> 1) & 7 : (row >> 2) & 3; }
+
+struct FastArgs {
+    GemmArgs g;
+    int ntm, ntn, items, nk_total, per;   // per = k-tiles per K split
+};
+
+template <bool KC>
+struct OperandStream {                   // this lane's DMA source pointers into one operand + the k-tile step
+    const float* p[FPCS];
+    long long step;
+    __device__ __forceinline__ void set(const float* base, long long ld, int row0, int k0, int wave, int lane) {
+        if (KC) {
+#pragma unroll
+            for (int pc = 0; pc < FPCS; ++pc) {
+                const int row = (wave * FPCS + pc) * FRP + lane / FCH;
+                p[pc] = base + (long long)(row0 + row) * ld + k0 + (((lane % FCH) ^ fswz(row)) << 2);
+            }
+            step = FBK;
+        } else {
+#pragma unroll
+            for (int pc = 0; pc < FPCS; ++pc) {
+                const int kr = (wave * FPCS + pc) * 2 + (lane >> 5);
+                p[pc] = base + (long long)(k0 + kr) * ld + row0 + ((lane & 31) << 2);
+            }
+            step = FBK * ld;
+        }
+    }
+    __device__ __forceinline__ void rewind(int nk) {
+#pragma unroll
+        for (int pc = 0; pc < FPCS; ++pc) p[pc] -= nk * step;
+    }
+    __device__ __forceinline__ void issue(unsigned tile, int wave) {      // tile: LDS byte address of the operand tile
+#pragma unroll
+        for (int pc = 0; pc < FPCS; ++pc) {
+            dma16(p[pc], tile + (wave * FPCS + pc) * 1024);  // 1 KiB pieces: FRP rows x FBK k, or 2 k x 128 rows
+            p[pc] += step;
+        }
+    }
+};
+
+#ifdef GEMM_CLOCK_PROBE
+__device__ unsigned long long gemm_probe[4 * 1024];     // dev-only: per workgroup: start, end (100 MHz), cycles, hw id
+#endif
+
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(256, FWGS)
+gemm_f32_fast_kernel(FastArgs fa) {
+#ifdef GEMM_CLOCK_PROBE
+    const unsigned long long pc0 = __builtin_amdgcn_s_memtime(), pr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    __shared__ __attribute__((aligned(16))) float stage0[STAGE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float stage1[STAGE_FLOATS];
+#if FNST == 3
+    __shared__ __attribute__((aligned(16))) float stage2[STAGE_FLOATS];
+#endif
+    const GemmArgs& g = fa.g;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int nwg = gridDim.x;
+    int slot = blockIdx.x;               // workgroups b, b+8, ... share an XCD: give each XCD a contiguous run of items
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = slot & 7, loc = slot >> 3;
+        slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    if (slot >= fa.items) return;
+    const int tiles = fa.ntm * fa.ntn;
+
+    // work item -> tile origin and K range (in k-tiles)
+    auto item_m0 = [&](int it) { return ((it % tiles) / fa.ntn) * 128; };
+    auto item_n0 = [&](int it) { return ((it % tiles) % fa.ntn) * 128; };
+    auto item_k0 = [&](int it) { return (it / tiles) * fa.per; };
+    auto item_nk = [&](int it) { return min(fa.per, fa.nk_total - (it / tiles) * fa.per); };
+
+    // loader state: the next k-tile to fetch
+    OperandStream<A_KC> sa;
+    OperandStream<B_KC> sb;
+    // K rotation: workgroup w walks its item's k-tiles starting at tile (w mod nk) and wraps.  Workgroups that run
+    // side by side then read different column ranges of their rows at any moment; started together on the same
+    // columns they all hit the same few memory channels (rows are a power of two apart): measured 11 % on K = 512.
+#ifndef GEMM_NO_ROT
+    auto item_rot = [&](int it) { return slot % item_nk(it); };
+#else
+    auto item_rot = [&](int it) { return 0; };
+#endif
+    int l_item = slot, l_left, l_wrap, l_nk;
+    auto open_item = [&]() {
+        l_nk = item_nk(l_item);
+        l_left = l_nk;
+        l_wrap = item_rot(l_item);
+        const int k0 = (item_k0(l_item) + l_wrap) * FBK;
+        sa.set(g.A, A_KC ? g.sam : g.sak, item_m0(l_item), k0, wave, lane);
+        sb.set(g.B, B_KC ? g.sbn : g.sbk, item_n0(l_item), k0, wave, lane);
+    };
+    open_item();
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    auto fetch = [&](const float* stage) -> bool {       // issue the DMA of the next k-tile (if any) into that stage
+        if (l_item >= fa.items) return false;
+        const unsigned st = lds_addr(stage);
+        sa.issue(st, uwave);
+        sb.issue(st + 128 * FBK * 4, uwave);
+        if (--l_left == 0) {
+            l_item += nwg;
+            if (l_item < fa.items) open_item();
+        } else if (l_left == l_wrap) {
+            sa.rewind(l_nk);
+            sb.rewind(l_nk);
+        }
+        return true;
+    };
+
+    f32x16 acc[2][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    };
+    zero_acc();
+
+    // fragment read offsets (floats) inside a stage
+    const int sw = fswz(i);
+    const int a_off = A_KC ? (wm + i) * FBK : wm + 2 * i;
+    const int b_off = 128 * FBK + (B_KC ? (wn + i) * FBK : wn + i);
+
+    struct Frag { float a0[4], a1[4], b0[4], b1[4]; };
+    auto load_frag = [&](Frag& f, const float* st, int gq) {
+        if (A_KC) {
+            const int c = (((2 * gq + h) ^ sw) << 2);
+            const float4 x0 = *reinterpret_cast<const float4*>(st + a_off + c);
+            const float4 x1 = *reinterpret_cast<const float4*>(st + a_off + 32 * FBK + c);
+            f.a0[0] = x0.x; f.a0[1] = x0.y; f.a0[2] = x0.z; f.a0[3] = x0.w;
+            f.a1[0] = x1.x; f.a1[1] = x1.y; f.a1[2] = x1.z; f.a1[3] = x1.w;
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float2 x = *reinterpret_cast<const float2*>(st + a_off + (8 * gq + 4 * h + s) * 128);
+                f.a0[s] = x.x; f.a1[s] = x.y;
+            }
+        }
+        if (B_KC) {
+            const int c = (((2 * gq + h) ^ sw) << 2);
+            const float4 y0 = *reinterpret_cast<const float4*>(st + b_off + c);
+            const float4 y1 = *reinterpret_cast<const float4*>(st + b_off + 32 * FBK + c);
+            f.b0[0] = y0.x; f.b0[1] = y0.y; f.b0[2] = y0.z; f.b0[3] = y0.w;
+            f.b1[0] = y1.x; f.b1[1] = y1.y; f.b1[2] = y1.z; f.b1[3] = y1.w;
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                f.b0[s] = st[b_off + (8 * gq + 4 * h + s) * 128];
+                f.b1[s] = st[b_off + (8 * gq + 4 * h + s) * 128 + 32];
+            }
+        }
+    };
+    auto mfma16 = [&](const Frag& f) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[s], f.b0[s], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[s], f.b1[s], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[s], f.b0[s], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[s], f.b1[s], acc[1][1], 0, 0, 0);
+        }
+    };
+    // fragments of group g+1 are read while group g is in the MFMA
+    // (sched_barrier pins the order: hipcc otherwise sinks each read group down to its use)
+    auto compute = [&](const float* st) {
+        Frag f0, f1;
+        load_frag(f0, st, 0);
+        load_frag(f1, st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (FBK == 32) {
+            load_frag(f0, st, 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma16(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (FBK == 32) {
+            load_frag(f1, st, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(f0);
+            mfma16(f1);
+        }
+    };
+
+    auto epilogue = [&](int it) {
+        const int m0 = item_m0(it), n0 = item_n0(it);
+        const bool first_split = it < tiles;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int n = n0 + wn + 32 * b + i;
+                const float bias = (g.bias && first_split) ? g.bias[n] : 0.f;
+                float* crow = g.C + n;
+                if (g.splitk > 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = mfma32_row(r, lane);
+                        const int m = m0 + wm + (A_KC ? 32 * a + rr : 2 * rr + a);
+                        atomicAdd(crow + (long long)m * g.ldc, g.alpha * acc[a][b][r] + bias);
+                    }
+                } else {
+                    float rv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = mfma32_row(r, lane);
+                        const int m = m0 + wm + (A_KC ? 32 * a + rr : 2 * rr + a);
+                        rv[r] = g.R ? g.R[(long long)m * g.ldr + n] : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = mfma32_row(r, lane);
+                        const int m = m0 + wm + (A_KC ? 32 * a + rr : 2 * rr + a);
+                        float v = g.alpha * acc[a][b][r] + bias + rv[r];
+                        if (g.relu) v = fmaxf(v, 0.f);
+                        crow[(long long)m * g.ldc] = v;
+                    }
+                }
+            }
+    };
+
+    int c_item = slot, c_left = item_nk(slot);
+    bool ahead = false;                  // a younger DMA (the stage after this one) is in flight and nothing else is
+    fetch(stage0);
+#if FNST == 3
+    ahead = fetch(stage1);
+#endif
+    // one k-tile: wait for its DMA, barrier (every wave is past its reads of the stage about to be refilled), start
+    // the DMA of the k-tile FNST-1 ahead, multiply; at the end of an item write it out.  false = stream done.
+    auto step = [&](float* cur, float* refill) -> bool {
+        // vmcnt: this stage's DMA has landed.  With 3 stages the next stage's 2*FPCS requests may stay in flight
+        // (requests retire in order); after an epilogue everything is drained (its stores are younger than them).
+        if (FNST == 3 && ahead) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * FPCS));
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();    // (bare barrier: __syncthreads() would add a vmcnt(0) fence)
+        asm volatile("" ::: "memory");
+        ahead = fetch(refill);
+        compute(cur);
+        if (--c_left == 0) {
+            epilogue(c_item);
+            ahead = false;
+            c_item += nwg;
+            if (c_item >= fa.items) return false;
+            c_left = item_nk(c_item);
+            zero_acc();
+        }
+        return true;
+    };
+    while (true) {
+#if FNST == 3
+        if (!step(stage0, stage2)) break;
+        if (!step(stage1, stage0)) break;
+        if (!step(stage2, stage1)) break;
+#else
+        if (!step(stage0, stage1)) break;
+        if (!step(stage1, stage0)) break;
+#endif
+    }
+#ifdef GEMM_CLOCK_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+        gemm_probe[4 * blockIdx.x + 0] = pr0;
+        gemm_probe[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        gemm_probe[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime() - pc0;
+        gemm_probe[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |    // HW_ID
+                                         ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32);  // XCC_ID
+    }
+#endif
 }
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -252,10 +572,33 @@ extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
     const bool va = aligned16(A) && (a_ld % 4 == 0) && (sA1 % 4 == 0) && (sA2 % 4 == 0) && ((a_kc ? K : M) % 4 == 0);
     const bool vb = aligned16(B) && (b_ld % 4 == 0) && (sB1 % 4 == 0) && (sB2 % 4 == 0) && ((b_kc ? K : N) % 4 == 0);
     g.vecA = va; g.vecB = vb;
+    hipStream_t s = (hipStream_t)stream;
+    static int fast_env = -1;
+    if (fast_env < 0) fast_env = getenv("JOVA_GEMM_NO_FAST") ? 0 : 1;
+    const bool fast = fast_env && nb1 == 1 && nb2 == 1 && M % 128 == 0 && N % 128 == 0 && K % FBK == 0 && K > 0 && va &&
+                      vb && aligned16(C) && (!residual || true);
+    if (fast) {
+        FastArgs fa;
+        fa.g = g;
+        fa.ntm = M / 128;
+        fa.ntn = N / 128;
+        fa.nk_total = K / FBK;
+        fa.per = (fa.nk_total + splitk - 1) / splitk;
+        const int nsplit = (fa.nk_total + fa.per - 1) / fa.per;     // splits that own at least one k-tile
+        fa.items = fa.ntm * fa.ntn * nsplit;
+        const int nwg = fa.items < 256 * FWGS ? fa.items : 256 * FWGS;   // persistent workgroups, FWGS per CU
+#define GEMM_FAST(AK, BK_) hipLaunchKernelGGL((gemm_f32_fast_kernel<AK, BK_>), dim3(nwg), dim3(256), 0, s, fa)
+        if (a_kc && b_kc) GEMM_FAST(true, true);
+        else if (a_kc && !b_kc) GEMM_FAST(true, false);
+        else if (!a_kc && b_kc) GEMM_FAST(false, true);
+        else GEMM_FAST(false, false);
+#undef GEMM_FAST
+        JOVA_CHECK_LAUNCH("gemm_f32_fast");
+        return JOVA_OK;
+    }
     const long long gz = (long long)nb1 * nb2 * splitk;
     JOVA_CHECK_ARG(gz <= 65535, "gemm: batch*splitk %lld exceeds grid.z", gz);
     dim3 grid((unsigned)((long long)cdiv(M, BM) * cdiv(N, BN)), 1, (unsigned)gz);
-    hipStream_t s = (hipStream_t)stream;
 #define GEMM_LAUNCH(AK, BK_, VA_, VB_) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, VA_, VB_>), grid, dim3(256), 0, s, g)
 #define GEMM_VEC(AK, BK_)                                                     \
     do {                                                                      \

@@ -28,7 +28,8 @@ def _load_sd(module, z, prefix):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("layout", ["kc_kc", "kc_rc", "rc_kc", "rc_rc"])
-@pytest.mark.parametrize("shape", [(5, 7, 3), (128, 128, 16), (130, 67, 75), (300, 194, 64), (257, 512, 242), (64, 1, 637)])
+@pytest.mark.parametrize("shape", [(5, 7, 3), (128, 128, 16), (130, 67, 75), (300, 194, 64), (257, 512, 242), (64, 1, 637),
+                                   (128, 128, 32), (256, 384, 96), (1280, 640, 160)])   # last three: aligned fast form
 def test_gemm_layouts(device, layout, shape):
     from jova_amd.nn import functional as F_
     M, N, K = shape
@@ -70,6 +71,14 @@ def test_gemm_batched_strided_and_splitk(device):
     a_d, b_d = a.to(device), b.to(device)
     F_.gemm(F_._addr(a_d), K, 1, F_._addr(b_d), 1, K, F_._addr(C), N, M, N, K, splitk=7)
     H.assert_close(C, (a.double() @ b.double().t() + 1).float(), tol=2e-6, what="splitk")
+    # aligned fast form, weight-gradient shape: more work items than persistent workgroups, ragged last K split
+    M, N, K = 1024, 1152, 32 * 37
+    a = torch.randn(K, M, generator=g)
+    b = torch.randn(K, N, generator=g)
+    C = torch.ones(M, N, device=device)
+    a_d, b_d = a.to(device), b.to(device)
+    F_.gemm(F_._addr(a_d), 1, M, F_._addr(b_d), N, 1, F_._addr(C), N, M, N, K, splitk=8)
+    H.assert_close(C, (a.double().t() @ b.double() + 1).float(), tol=2e-6, what="splitk fast")
 
 
 # ------------------------------------------------------------------------------------------------ graph stack
