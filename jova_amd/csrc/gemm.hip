@@ -256,7 +256,7 @@ gemm_f32_kernel(GemmArgs g) {
 #define FNST 3               // LDS stages (each its own array)
 #endif
 #ifndef FWGS
-#define FWGS 3               // persistent workgroups per CU
+#define FWGS 2               // persistent workgroups per CU
 #endif
 #define FCH (FBK / 4)                    // 16-byte chunks per K-contiguous row
 #define FRP (64 / FCH)                   // rows per 1 KiB DMA piece of a K-contiguous operand
@@ -275,9 +275,15 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {            // LDS
 }
 __device__ __forceinline__ int fswz(int row) { return FBK == 32 ? (row >> 1) & 7 : (row >> 2) & 3; }
 
+// Work items of the fast form.  Items [0, full) are whole output tiles (tile = item, all of K, plain epilogue).
+// Items from `full` on are K-parts of the remaining `rem` tiles: part = (item - full) / rem covers k-tiles
+// [part * per, ...) of tile full + (item - full) % rem and ADDS its partial sum to C with float atomics (part 0 also
+// adds bias / residual).  Two uses: split-K weight gradients (full = 0, rem = all tiles, C accumulates), and the
+// ragged last round of a persistent grid (the host zeroes those rows of C first) -- without it a [35k x 512] output
+// (1116 tiles on 512 workgroups) costs 3 rounds for 2.2 rounds of work.
 struct FastArgs {
     GemmArgs g;
-    int ntm, ntn, items, nk_total, per;   // per = k-tiles per K split
+    int ntm, ntn, items, nk_total, per, full, rem;
 };
 
 template <bool KC>
@@ -340,25 +346,21 @@ gemm_f32_fast_kernel(FastArgs fa) {
         slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
     if (slot >= fa.items) return;
-    const int tiles = fa.ntm * fa.ntn;
 
     // work item -> tile origin and K range (in k-tiles)
-    auto item_m0 = [&](int it) { return ((it % tiles) / fa.ntn) * 128; };
-    auto item_n0 = [&](int it) { return ((it % tiles) % fa.ntn) * 128; };
-    auto item_k0 = [&](int it) { return (it / tiles) * fa.per; };
-    auto item_nk = [&](int it) { return min(fa.per, fa.nk_total - (it / tiles) * fa.per); };
+    auto item_tile = [&](int it) { return it < fa.full ? it : fa.full + (it - fa.full) % fa.rem; };
+    auto item_part = [&](int it) { return it < fa.full ? 0 : (it - fa.full) / fa.rem; };
+    auto item_m0 = [&](int it) { return (item_tile(it) / fa.ntn) * 128; };
+    auto item_n0 = [&](int it) { return (item_tile(it) % fa.ntn) * 128; };
+    auto item_k0 = [&](int it) { return item_part(it) * fa.per; };
+    auto item_nk = [&](int it) { return it < fa.full ? fa.nk_total : min(fa.per, fa.nk_total - item_part(it) * fa.per); };
 
     // loader state: the next k-tile to fetch
     OperandStream<A_KC> sa;
     OperandStream<B_KC> sb;
-    // K rotation: workgroup w walks its item's k-tiles starting at tile (w mod nk) and wraps.  Workgroups that run
-    // side by side then read different column ranges of their rows at any moment; started together on the same
-    // columns they all hit the same few memory channels (rows are a power of two apart): measured 11 % on K = 512.
-#ifndef GEMM_NO_ROT
-    auto item_rot = [&](int it) { return slot % item_nk(it); };
-#else
-    auto item_rot = [&](int it) { return 0; };
-#endif
+    // (Starting each workgroup at a different k-tile of its item -- so that neighbours read different columns of
+    // their power-of-two-strided rows -- was measured and bought nothing; l_wrap stays 0.)
+    auto item_rot = [&](int) { return 0; };
     int l_item = slot, l_left, l_wrap, l_nk;
     auto open_item = [&]() {
         l_nk = item_nk(l_item);
@@ -464,7 +466,8 @@ gemm_f32_fast_kernel(FastArgs fa) {
 
     auto epilogue = [&](int it) {
         const int m0 = item_m0(it), n0 = item_n0(it);
-        const bool first_split = it < tiles;
+        const bool first_split = item_part(it) == 0;
+        const bool partial = it >= fa.full;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -472,12 +475,14 @@ gemm_f32_fast_kernel(FastArgs fa) {
                 const int n = n0 + wn + 32 * b + i;
                 const float bias = (g.bias && first_split) ? g.bias[n] : 0.f;
                 float* crow = g.C + n;
-                if (g.splitk > 1) {
+                if (partial) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int rr = mfma32_row(r, lane);
                         const int m = m0 + wm + (A_KC ? 32 * a + rr : 2 * rr + a);
-                        atomicAdd(crow + (long long)m * g.ldc, g.alpha * acc[a][b][r] + bias);
+                        float v = g.alpha * acc[a][b][r] + bias;
+                        if (g.R && first_split) v += g.R[(long long)m * g.ldr + n];
+                        atomicAdd(crow + (long long)m * g.ldc, v);
                     }
                 } else {
                     float rv[16];
@@ -583,10 +588,33 @@ extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
         fa.ntm = M / 128;
         fa.ntn = N / 128;
         fa.nk_total = K / FBK;
-        fa.per = (fa.nk_total + splitk - 1) / splitk;
-        const int nsplit = (fa.nk_total + fa.per - 1) / fa.per;     // splits that own at least one k-tile
-        fa.items = fa.ntm * fa.ntn * nsplit;
-        const int nwg = fa.items < 256 * FWGS ? fa.items : 256 * FWGS;   // persistent workgroups, FWGS per CU
+        const int tiles = fa.ntm * fa.ntn, slots = 256 * FWGS;       // persistent workgroups, FWGS per CU
+        if (splitk > 1) {                                            // explicit split-K: C accumulates
+            fa.per = (fa.nk_total + splitk - 1) / splitk;
+            fa.full = 0;
+            fa.rem = tiles;
+            fa.items = tiles * ((fa.nk_total + fa.per - 1) / fa.per);    // splits that own at least one k-tile
+        } else {
+            fa.full = tiles;
+            fa.rem = 0;
+            fa.per = fa.nk_total;
+            fa.items = tiles;
+            // ragged last round: split its tiles along K over the idle workgroups (needs C rows zeroed first, so C
+            // must not double as the residual, be dense, and ReLU cannot apply to partial sums)
+            const int rem = tiles % slots;
+            const int parts = rem > 0 ? slots / rem : 1;
+            const int max_parts = fa.nk_total / 8;                   // at least 8 k-tiles per part
+            const int use = parts < max_parts ? parts : max_parts;
+            if (tiles > slots && use >= 2 && !relu && residual != C && ldc == N) {
+                fa.full = tiles - rem;
+                fa.rem = rem;
+                fa.per = (fa.nk_total + use - 1) / use;
+                fa.items = fa.full + rem * ((fa.nk_total + fa.per - 1) / fa.per);
+                const long long row0 = (long long)(fa.full / fa.ntn) * 128;
+                JOVA_CHECK_HIP(hipMemsetAsync(C + row0 * ldc, 0, (size_t)(M - row0) * ldc * sizeof(float), s));
+            }
+        }
+        const int nwg = fa.items < slots ? fa.items : slots;
 #define GEMM_FAST(AK, BK_) hipLaunchKernelGGL((gemm_f32_fast_kernel<AK, BK_>), dim3(nwg), dim3(256), 0, s, fa)
         if (a_kc && b_kc) GEMM_FAST(true, true);
         else if (a_kc && !b_kc) GEMM_FAST(true, false);

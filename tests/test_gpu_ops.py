@@ -79,6 +79,18 @@ def test_gemm_batched_strided_and_splitk(device):
     a_d, b_d = a.to(device), b.to(device)
     F_.gemm(F_._addr(a_d), 1, M, F_._addr(b_d), N, 1, F_._addr(C), N, M, N, K, splitk=8)
     H.assert_close(C, (a.double().t() @ b.double() + 1).float(), tol=2e-6, what="splitk fast")
+    # aligned fast form, ragged last round: 520 tiles on 512 persistent workgroups -> the last 8 tiles are split along K
+    # and accumulated with atomics onto zeroed rows; bias + residual come from part 0
+    M, N, K = 8320, 1024, 512
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    a_d, b_d, bias_d, res_d = a.to(device), b.to(device), bias.to(device), res.to(device)
+    C = torch.full((M, N), float("nan"), device=device)
+    F_.gemm(F_._addr(a_d), K, 1, F_._addr(b_d), 1, K, F_._addr(C), N, M, N, K, bias=F_.P(bias_d),
+            residual=F_._addr(res_d), ldr=N)
+    H.assert_close(C, (a.double() @ b.double().t() + bias.double() + res.double()).float(), tol=2e-6, what="ragged tail")
 
 
 # ------------------------------------------------------------------------------------------------ graph stack
