@@ -228,8 +228,10 @@ gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mbase + mfma32_row(r, lane);
-                    float v = g.alpha * acc[a][b][r] + bias + rv[r];
-                    if (g.relu) v = fmaxf(v, 0.f);
+                    float v = g.alpha * acc[a][b][r] + bias;
+                    if (g.relu == 2) v = rv[r] > 0.f ? v : 0.f;      // ReLU backward: the "residual" is the mask source
+                    else v += rv[r];
+                    if (g.relu == 1) v = fmaxf(v, 0.f);
                     if (m < g.M && nok && (!(GEMM_ABL & 2) || v == 1.2345e-30f)) C[(long long)m * g.ldc + n] = v;
                 }
             }
@@ -496,8 +498,10 @@ gemm_f32_fast_kernel(FastArgs fa) {
                     for (int r = 0; r < 16; ++r) {
                         const int rr = mfma32_row(r, lane);
                         const int m = m0 + wm + (A_KC ? 32 * a + rr : 2 * rr + a);
-                        float v = g.alpha * acc[a][b][r] + bias + rv[r];
-                        if (g.relu) v = fmaxf(v, 0.f);
+                        float v = g.alpha * acc[a][b][r] + bias;
+                        if (g.relu == 2) v = rv[r] > 0.f ? v : 0.f;
+                        else v += rv[r];
+                        if (g.relu == 1) v = fmaxf(v, 0.f);
                         crow[(long long)m * g.ldc] = v;
                     }
                 }
@@ -563,6 +567,7 @@ extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
     JOVA_CHECK_ARG(sam == 1 || sak == 1, "gemm: A needs a unit stride (sam=%lld sak=%lld)", (long long)sam, (long long)sak);
     JOVA_CHECK_ARG(sbk == 1 || sbn == 1, "gemm: B needs a unit stride (sbk=%lld sbn=%lld)", (long long)sbk, (long long)sbn);
     JOVA_CHECK_ARG(splitk >= 1 && (splitk == 1 || (!residual && !relu)), "gemm: split-K excludes residual/relu");
+    JOVA_CHECK_ARG(relu >= 0 && relu <= 2 && (relu != 2 || residual), "gemm: relu = 2 (mask) needs the mask source as residual");
     if (M == 0 || N == 0) return JOVA_OK;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.R = residual;

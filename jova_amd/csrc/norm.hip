@@ -22,19 +22,36 @@ colreduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, cons
         if (MODE == 1) { mu = mean_rstd[col]; rs = mean_rstd[c + col]; }
         // fp64 accumulation element by element: sum(x^2)/n - mean^2 cancels catastrophically in fp32 when
         // |mean| >> std (e.g. the 279-segment view sums that feed JointAttention's BatchNorm)
-        for (long long r = r0 + ty; r < r1; r += 4) {
+        // four rows in flight per thread (independent loads first, fp64 adds after)
+        auto add = [&](float xv, float gv, float yv) {
             if (MODE == 0) {
-                const double v = (double)x[r * ld + col];
+                const double v = (double)xv;
                 s0 += v;
                 s1 += v * v;
             } else if (MODE == 1) {
-                float g = dy[r * ld + col];
-                if (y && !(y[r * ld + col] > 0.f)) g = 0.f;
+                const float g = (y && !(yv > 0.f)) ? 0.f : gv;
                 s0 += (double)g;
-                s1 += (double)g * (double)((x[r * ld + col] - mu) * rs);
+                s1 += (double)g * (double)((xv - mu) * rs);
             } else {
-                s0 += (double)x[r * ld + col];
+                s0 += (double)xv;
             }
+        };
+        long long r = r0 + ty;
+        for (; r + 12 < r1; r += 16) {
+            float xv[4], gv[4], yv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long o = (r + 4 * u) * ld + col;
+                xv[u] = x[o];
+                gv[u] = MODE == 1 ? dy[o] : 0.f;
+                yv[u] = (MODE == 1 && y) ? y[o] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add(xv[u], gv[u], yv[u]);
+        }
+        for (; r < r1; r += 4) {
+            const long long o = r * ld + col;
+            add(x[o], MODE == 1 ? dy[o] : 0.f, (MODE == 1 && y) ? y[o] : 1.f);
         }
     }
     red[0][ty][tx] = s0;

@@ -275,10 +275,15 @@ def linear_fwd(x2d, w, b, out2d, relu=False, residual=None, tag=None):
          residual=_addr(residual) if residual is not None else None, ldr=N, relu=relu, tag=tag)
 
 
-def linear_bwd_data(dy2d, w, dx2d, residual=None):
-    """dx[M,K] = dy[M,N] @ w[N,K] (+ residual)."""
+def linear_bwd_data(dy2d, w, dx2d, residual=None, relu_mask=None):
+    """dx[M,K] = dy[M,N] @ w[N,K] (+ residual), or zeroed where relu_mask[M,K] <= 0 (fused ReLU backward)."""
     M, N = dy2d.shape
     K = w.shape[1]
+    if relu_mask is not None:
+        if residual is not None:
+            raise ValueError("linear_bwd_data: residual and relu_mask exclude each other")
+        gemm(_addr(dy2d), N, 1, _addr(w), K, 1, _addr(dx2d), K, M, K, N, residual=_addr(relu_mask), ldr=K, relu=2)
+        return
     gemm(_addr(dy2d), N, 1, _addr(w), K, 1, _addr(dx2d), K, M, K, N,
          residual=_addr(residual) if residual is not None else None, ldr=K)
 
@@ -571,8 +576,7 @@ class JointAttentionFunction(torch.autograd.Function):
             # FFN: f = hid @ w2^T + b2 ; hid = relu(x1 @ w1^T + b1)
             linear_bwd_weight(dz2, hid, tg[base + 6], tg[base + 7])
             dhid = _empty((T, inner), ref)
-            linear_bwd_data(dz2, w2, dhid)
-            call("jova_relu_bwd", P(dhid), P(hid), dhid.numel(), P(dhid), stream())
+            linear_bwd_data(dz2, w2, dhid, relu_mask=hid)          # ReLU backward fused into the epilogue
             linear_bwd_weight(dhid, x1, tg[base + 4], tg[base + 5])
             dx1 = _empty((T, L), ref)
             linear_bwd_data(dhid, w1, dx1, residual=dz2)          # + residual branch of LN2
