@@ -14,16 +14,10 @@
 #include "jova_hip.h"
 #include <stdlib.h>
 
-#define BM 128
-#define BN 128
 #define BK 32
 #define LDS_KC (BK + 1)      // [row][k] image, odd stride: conflict-free ds_read_b32 down a column
-#define LDS_RC (BM + 4)      // [k][row] image, 16-byte aligned rows
 #ifndef GEMM_WGS
 #define GEMM_WGS 3           // workgroups per CU the register budget is held to
-#endif
-#ifndef GEMM_ABL
-#define GEMM_ABL 0           // dev-only ablation bits (tools/scratch/gemm_lab.hip); 0 in the product
 #endif
 
 struct GemmArgs {
@@ -78,71 +72,77 @@ __device__ __forceinline__ float4 masked(const Quad& q) {
     return r;
 }
 
+// Workgroup shape: W waves, square tile TS = 32 W (64, 96 or 128): wave w owns rows [32w, 32w+32) of the tile and all
+// of its TS columns (W accumulators).  The host picks W per launch: the per-(b,h) attention products have M = N = S
+// (239..279), which a 128-tile pads to 256 or 384 but a 96-tile to 288; narrow outputs (the protein MLP, N = 242) get
+// more, smaller workgroups so that every CU has work.
+//
 // Operand tile loader.  KC = true: the operand is K-contiguous (element (row,k) at base[row*srow + k]);
-// thread t covers rows t/8 + 32p (p < 4), k-quad (t%8)*4: 8 lanes read one full 128-byte line of a row.
-// KC = false: row-contiguous (element at base[k*sk + row]); thread t covers k = t/32 + 8p, row-quad (t%32)*4.
-template <bool KC, bool VEC>
+// thread t covers rows t/8 + 8W p (p < 4), k-quad (t%8)*4: 8 lanes read one full 128-byte line of a row.
+// KC = false: row-contiguous (element at base[k*sk + row]); thread t covers k = t/(8W) + 8p, row-quad (t%(8W))*4.
+template <bool KC, bool VEC, int W>
 __device__ __forceinline__ void load_operand(const float* __restrict__ base, long long srow, long long sk, int row0,
                                              int nrows, int k0, int kend, int tid, Quad (&v)[4]) {
     if (KC) {
         const int kq = (tid & 7) * 4;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int row = row0 + (tid >> 3) + 32 * p;
+            const int row = row0 + (tid >> 3) + 8 * W * p;
             const int nv = row < nrows ? kend - (k0 + kq) : 0;
             v[p] = load4<VEC>(base, (long long)row * srow + k0 + kq, nv);
         }
     } else {
-        const int rq = (tid & 31) * 4;
+        const int rq = (tid % (8 * W)) * 4;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int k = k0 + (tid >> 5) + 8 * p;
+            const int k = k0 + tid / (8 * W) + 8 * p;
             const int nv = k < kend ? nrows - (row0 + rq) : 0;
             v[p] = load4<VEC>(base, (long long)k * sk + row0 + rq, nv);
         }
     }
 }
 
-template <bool KC>
+template <bool KC, int W>
 __device__ __forceinline__ void store_operand(float* __restrict__ S, int tid, const Quad (&v)[4]) {
     if (KC) {
         const int kq = (tid & 7) * 4;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const float4 m = masked(v[p]);
-            float* d = S + ((tid >> 3) + 32 * p) * LDS_KC + kq;
+            float* d = S + ((tid >> 3) + 8 * W * p) * LDS_KC + kq;
             d[0] = m.x; d[1] = m.y; d[2] = m.z; d[3] = m.w;
         }
     } else {
-        const int rq = (tid & 31) * 4;
+        const int rq = (tid % (8 * W)) * 4;
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-            *reinterpret_cast<float4*>(S + ((tid >> 5) + 8 * p) * LDS_RC + rq) = masked(v[p]);
+            *reinterpret_cast<float4*>(S + (tid / (8 * W) + 8 * p) * (32 * W + 4) + rq) = masked(v[p]);
     }
 }
 
-template <bool KC>
+template <bool KC, int W>
 __device__ __forceinline__ float frag(const float* __restrict__ S, int row, int k) {
-    return KC ? S[row * LDS_KC + k] : S[k * LDS_RC + row];
+    return KC ? S[row * LDS_KC + k] : S[k * (32 * W + 4) + row];
 }
 
-template <bool A_KC, bool B_KC, bool VA, bool VB>
-__global__ void __launch_bounds__(256, GEMM_WGS)      // 3 workgroups per CU: <= 168 VGPR+AGPR
+template <bool A_KC, bool B_KC, bool VA, bool VB, int W>
+__global__ void __launch_bounds__(64 * W, W == 4 ? GEMM_WGS : 4)
 gemm_f32_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[A_KC ? BM * LDS_KC : BK * LDS_RC];
-    __shared__ __attribute__((aligned(16))) float Bs[B_KC ? BN * LDS_KC : BK * LDS_RC];
+    constexpr int TS = 32 * W;
+    __shared__ __attribute__((aligned(16))) float As[A_KC ? TS * LDS_KC : BK * (TS + 4)];
+    __shared__ __attribute__((aligned(16))) float Bs[B_KC ? TS * LDS_KC : BK * (TS + 4)];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // Tile order: n fastest (the tiles that share an A row-panel run back to back), and the linear tile id is
     // remapped so that each XCD (workgroups b, b+8, ... share one) walks a contiguous chunk of that order: the
     // A panel is then fetched once into ONE L2 instead of eight.
-    const int ntn = (g.N + BN - 1) / BN;
+    const int ntn = (g.N + TS - 1) / TS;
     const int nwg = gridDim.x;
     int pid = blockIdx.x;
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = pid & 7, loc = pid >> 3;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int m0 = (pid / ntn) * BM, n0 = (pid % ntn) * BN;
+    const int m0 = (pid / ntn) * TS, n0 = (pid % ntn) * TS;
     const int z = blockIdx.z / g.splitk, ks = blockIdx.z % g.splitk;
     const int z1 = z / g.nb2, z2 = z % g.nb2;
     const float* A = g.A + z1 * g.sA1 + z2 * g.sA2;
@@ -153,89 +153,79 @@ gemm_f32_kernel(GemmArgs g) {
     const int kbeg = ks * per * BK;
     const int kend = min(g.K, (ks + 1) * per * BK);
     const int nt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = wave * 32;
     const int i = lane & 31, h = lane >> 5;
 
-    f32x16 acc[2][2];
+    f32x16 acc[W];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < W; ++b)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
 
-    // Register prefetch: tile t+1 is loaded into registers while tile t is multiplied out of LDS.  (Measured on
-    // MI355X: double-buffered LDS with one barrier per tile and hand-pipelined ds_read_b128 fragments were both
-    // slower than this form at the 2-3 workgroups/CU it runs at -- profiles/r01_gemm_notes.md.)
+    // Register prefetch: tile t+1 is loaded into registers while tile t is multiplied out of LDS.
     Quad va[4], vb[4];
     if (nt > 0) {
-        load_operand<A_KC, VA>(A, g.sam, g.sak, m0, g.M, kbeg, kend, tid, va);
-        load_operand<B_KC, VB>(B, g.sbn, g.sbk, n0, g.N, kbeg, kend, tid, vb);
+        load_operand<A_KC, VA, W>(A, g.sam, g.sak, m0, g.M, kbeg, kend, tid, va);
+        load_operand<B_KC, VB, W>(B, g.sbn, g.sbk, n0, g.N, kbeg, kend, tid, vb);
     }
     for (int t = 0; t < nt; ++t) {
-        if (!(GEMM_ABL & 4) || t == 0) {
-            __syncthreads();
-            store_operand<A_KC>(As, tid, va);
-            store_operand<B_KC>(Bs, tid, vb);
-            __syncthreads();
-        }
-        if (t + 1 < nt && !(GEMM_ABL & 1)) {
-            load_operand<A_KC, VA>(A, g.sam, g.sak, m0, g.M, kbeg + (t + 1) * BK, kend, tid, va);
-            load_operand<B_KC, VB>(B, g.sbn, g.sbk, n0, g.N, kbeg + (t + 1) * BK, kend, tid, vb);
+        __syncthreads();
+        store_operand<A_KC, W>(As, tid, va);
+        store_operand<B_KC, W>(Bs, tid, vb);
+        __syncthreads();
+        if (t + 1 < nt) {
+            load_operand<A_KC, VA, W>(A, g.sam, g.sak, m0, g.M, kbeg + (t + 1) * BK, kend, tid, va);
+            load_operand<B_KC, VB, W>(B, g.sbn, g.sbk, n0, g.N, kbeg + (t + 1) * BK, kend, tid, vb);
         }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = frag<A_KC>(As, wm + i, kk + h);
-            const float a1 = frag<A_KC>(As, wm + 32 + i, kk + h);
-            const float b0 = frag<B_KC>(Bs, wn + i, kk + h);
-            const float b1 = frag<B_KC>(Bs, wn + 32 + i, kk + h);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            const float a0 = frag<A_KC, W>(As, wm + i, kk + h);
+            float bv[W];
+#pragma unroll
+            for (int b = 0; b < W; ++b) bv[b] = frag<B_KC, W>(Bs, 32 * b + i, kk + h);
+#pragma unroll
+            for (int b = 0; b < W; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[b], acc[b], 0, 0, 0);
         }
     }
 
     float* C = g.C + z1 * g.sC1 + z2 * g.sC2;
     const float* R = g.R ? g.R + z1 * g.sC1 + z2 * g.sC2 : nullptr;
+    const int mbase = m0 + wm;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < W; ++b) {
+        const int n = n0 + 32 * b + i;
+        const bool nok = n < g.N;
+        const int nc = nok ? n : g.N - 1;
+        const float bias = (g.bias && ks == 0) ? g.bias[nc] : 0.f;
+        if (g.splitk > 1) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int n = n0 + wn + 32 * b + i;
-            const bool nok = n < g.N;
-            const int nc = nok ? n : g.N - 1;
-            const float bias = (g.bias && ks == 0) ? g.bias[nc] : 0.f;
-            const int mbase = m0 + wm + 32 * a;
-            if (g.splitk > 1) {
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + mfma32_row(r, lane);
+                if (m < g.M && nok) atomicAdd(&C[(long long)m * g.ldc + n], g.alpha * acc[b][r] + bias);
+            }
+        } else {
+            float rv[16];
+            if (R) {            // unconditional (clamped) residual loads: all 16 in flight together
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = mbase + mfma32_row(r, lane);
-                    if (m < g.M && nok) atomicAdd(&C[(long long)m * g.ldc + n], g.alpha * acc[a][b][r] + bias);
+                    const int m = min(mbase + mfma32_row(r, lane), g.M - 1);
+                    rv[r] = R[(long long)m * g.ldr + nc];
                 }
             } else {
-                float rv[16];
-                if (R) {            // unconditional (clamped) residual loads: all 16 in flight together
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = min(mbase + mfma32_row(r, lane), g.M - 1);
-                        rv[r] = R[(long long)m * g.ldr + nc];
-                    }
-                } else {
+                for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mbase + mfma32_row(r, lane);
-                    float v = g.alpha * acc[a][b][r] + bias;
-                    if (g.relu == 2) v = rv[r] > 0.f ? v : 0.f;      // ReLU backward: the "residual" is the mask source
-                    else v += rv[r];
-                    if (g.relu == 1) v = fmaxf(v, 0.f);
-                    if (m < g.M && nok && (!(GEMM_ABL & 2) || v == 1.2345e-30f)) C[(long long)m * g.ldc + n] = v;
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + mfma32_row(r, lane);
+                float v = g.alpha * acc[b][r] + bias;
+                if (g.relu == 2) v = rv[r] > 0.f ? v : 0.f;      // ReLU backward: the "residual" is the mask source
+                else v += rv[r];
+                if (g.relu == 1) v = fmaxf(v, 0.f);
+                if (m < g.M && nok) C[(long long)m * g.ldc + n] = v;
             }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ aligned fast form
@@ -631,14 +621,42 @@ extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
     }
     const long long gz = (long long)nb1 * nb2 * splitk;
     JOVA_CHECK_ARG(gz <= 65535, "gemm: batch*splitk %lld exceeds grid.z", gz);
-    dim3 grid((unsigned)((long long)cdiv(M, BM) * cdiv(N, BN)), 1, (unsigned)gz);
-#define GEMM_LAUNCH(AK, BK_, VA_, VB_) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, VA_, VB_>), grid, dim3(256), 0, s, g)
+    // tile size: least padded work (smaller tiles pay a little more staging per flop), then enough workgroups for
+    // every CU; JOVA_GEMM_W pins it (tests)
+    static int w_env = -1;
+    if (w_env < 0) {
+        const char* e = getenv("JOVA_GEMM_W");
+        w_env = e ? atoi(e) : 0;
+    }
+    int Wsel = 4;
+    if (w_env >= 2 && w_env <= 4) Wsel = w_env;
+    else {
+        double best = 1e300;
+        for (int w = 4; w >= 2; --w) {
+            const long long ts = 32 * w;
+            const long long wgs = (long long)cdiv(M, ts) * cdiv(N, ts) * gz;
+            // time estimate in units of one SIMD's work: all 1024 SIMDs busy, or one wave's share of a tile
+            const double total = (double)wgs * ts * ts / 1024.0, alone = (double)ts * ts / w;
+            const double cost = (total > alone ? total : alone) * (w == 4 ? 1.0 : (w == 3 ? 1.06 : 1.15));
+            if (cost < best) { best = cost; Wsel = w; }
+        }
+    }
+    const long long ts = 32 * Wsel;
+    dim3 grid((unsigned)((long long)cdiv(M, ts) * cdiv(N, ts)), 1, (unsigned)gz);
+#define GEMM_LAUNCH(AK, BK_, VA_, VB_, W_) \
+    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, VA_, VB_, W_>), grid, dim3(64 * W_), 0, s, g)
+#define GEMM_W(AK, BK_, VA_, VB_)                                              \
+    do {                                                                       \
+        if (Wsel == 4) GEMM_LAUNCH(AK, BK_, VA_, VB_, 4);                      \
+        else if (Wsel == 3) GEMM_LAUNCH(AK, BK_, VA_, VB_, 3);                 \
+        else GEMM_LAUNCH(AK, BK_, VA_, VB_, 2);                                \
+    } while (0)
 #define GEMM_VEC(AK, BK_)                                                     \
     do {                                                                      \
-        if (va && vb) GEMM_LAUNCH(AK, BK_, true, true);                       \
-        else if (va) GEMM_LAUNCH(AK, BK_, true, false);                       \
-        else if (vb) GEMM_LAUNCH(AK, BK_, false, true);                       \
-        else GEMM_LAUNCH(AK, BK_, false, false);                              \
+        if (va && vb) GEMM_W(AK, BK_, true, true);                            \
+        else if (va) GEMM_W(AK, BK_, true, false);                            \
+        else if (vb) GEMM_W(AK, BK_, false, true);                            \
+        else GEMM_W(AK, BK_, false, false);                                   \
     } while (0)
     if (a_kc && b_kc) GEMM_VEC(true, true);
     else if (a_kc && !b_kc) GEMM_VEC(true, false);
