@@ -619,7 +619,7 @@ extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
         JOVA_CHECK_LAUNCH("gemm_f32_fast");
         return JOVA_OK;
     }
-    const long long gz = (long long)nb1 * nb2 * splitk;
+    long long gz = (long long)nb1 * nb2 * splitk;
     JOVA_CHECK_ARG(gz <= 65535, "gemm: batch*splitk %lld exceeds grid.z", gz);
     // tile size: least padded work (smaller tiles pay a little more staging per flop), then enough workgroups for
     // every CU; JOVA_GEMM_W pins it (tests)
@@ -642,6 +642,19 @@ extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
         }
     }
     const long long ts = 32 * Wsel;
+    // a lone small product with a long K (the FC head at M = 128): split K over otherwise idle CUs, partial sums
+    // added onto a zeroed C (bias comes with split 0; ReLU / residual cannot apply to partial sums)
+    if (splitk == 1 && gz == 1 && !relu && !residual && K >= 256) {
+        const long long waves = (long long)cdiv(M, ts) * cdiv(N, ts) * Wsel;
+        int sk = (int)(1024 / (waves > 0 ? waves : 1));
+        if (sk > K / 64) sk = K / 64;
+        if (sk > 32) sk = 32;
+        if (sk >= 2) {
+            JOVA_CHECK_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s));
+            g.splitk = sk;
+            gz = sk;
+        }
+    }
     dim3 grid((unsigned)((long long)cdiv(M, ts) * cdiv(N, ts)), 1, (unsigned)gz);
 #define GEMM_LAUNCH(AK, BK_, VA_, VB_, W_) \
     hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, VA_, VB_, W_>), grid, dim3(64 * W_), 0, s, g)
