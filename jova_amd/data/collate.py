@@ -58,19 +58,26 @@ def process_gconv_view_data(mols, device):
 class DtiBatch(object):
     """One collated mini-batch, resident on the device."""
 
-    def __init__(self, ecfp, glist, prot_names, y, w, prot_input=None):
+    def __init__(self, ecfp, glist, prot_names, y, w, prot_input=None, psc=None):
         self.ecfp, self.glist, self.prot_names, self.y, self.w = ecfp, glist, prot_names, y, w
         self.prot_input = prot_input
+        self.psc = psc
         self.batch_size = ecfp.shape[0]
 
     def model_input(self):
-        """X = compound views + protein views, as assembled at train_joint_attn.py:441-453."""
+        """X = compound views + protein views, as assembled at train_joint_attn.py:441-453: embedding-based protein
+        views take the name list (element 2 of the collator's tuple), the ``psc`` view the descriptor tensor
+        (element 1); order = c_views + p_views, here ecfp8, gconv, pcnn2d[, psc]."""
         prot = self.prot_input if self.prot_input is not None else self.prot_names
-        return [self.ecfp, (self.glist, self.batch_size), prot]
+        x = [self.ecfp, (self.glist, self.batch_size), prot]
+        if self.psc is not None:
+            x.append(self.psc)
+        return x
 
 
-def collate_pairs(pool, conv_mols, mol_ids, prot_ids, y, w, device, prot2vec=None):
-    """Synthetic-pool pairs -> DtiBatch.  ``prot2vec`` (optional module) pre-resolves protein names to table rows."""
+def collate_pairs(pool, conv_mols, mol_ids, prot_ids, y, w, device, prot2vec=None, with_psc=False):
+    """Synthetic-pool pairs -> DtiBatch.  ``prot2vec`` (optional module) pre-resolves protein names to table rows;
+    ``with_psc`` adds the [B,8421] descriptor tensor of the ``psc`` view (process_ecfp_view_data, data.py:190-212)."""
     glist = process_gconv_view_data([conv_mols[i] for i in mol_ids], device)
     ecfp = torch.from_numpy(pool.ecfp[mol_ids]).to(device, non_blocking=True)
     names = [("synthetic", pool.prot_names[i]) for i in prot_ids]
@@ -79,4 +86,5 @@ def collate_pairs(pool, conv_mols, mol_ids, prot_ids, y, w, device, prot2vec=Non
     prot_input = None
     if prot2vec is not None and device.type == "cuda":
         prot_input = prot2vec._resident_table(device).batch(names, device)
-    return DtiBatch(ecfp, glist, names, yt, wt, prot_input)
+    psc = torch.from_numpy(pool.psc[prot_ids]).to(device, non_blocking=True) if with_psc else None
+    return DtiBatch(ecfp, glist, names, yt, wt, prot_input, psc)

@@ -139,6 +139,18 @@ class SyntheticPool(object):
         self.protein_profile = {name: make_protein(rng, s, vocab)
                                 for name, s in zip(self.prot_names, spec["segs"](rng, n_prots))}
         self.ecfp = (rng.uniform(size=(n_mols, 1024)) < 0.06).astype(np.float32)
+        self._psc = None
+        self._psc_seed = seed
+
+    @property
+    def psc(self):
+        """[n_prots, 8421] float32 protein-sequence-composition descriptors (the ``psc`` view; the real tables are
+        z-scored composition counts, data/*/prot_desc.csv): seeded N(0,1), made on first use, from a stream of its own
+        so that pools of one seed are identical whether or not the view is used."""
+        if self._psc is None:
+            rng = np.random.RandomState(self._psc_seed + 7919)
+            self._psc = rng.normal(size=(len(self.prot_names), 8421)).astype(np.float32)
+        return self._psc
 
     def sample_pairs(self, rng, batch_size):
         """-> (mol_ids [B], prot_ids [B], y [B,1] float64, w [B,1] float64)."""

@@ -195,7 +195,8 @@ def joint_attention(inputs, p, num_heads, num_layers=1, prefix=""):
 def dti_forward(p, batch, num_heads, n_pcnn_layers, n_lin):
     """create_integrated_net for views ecfp8-gconv__pcnn2d (train_joint_attn.py:188-243), dprob 0.
 
-    p: state dict with the reference's keys; batch: dict(ecfp [B,1024], glist, prot_idx [B,P,w]).
+    p: state dict with the reference's keys; batch: dict(ecfp [B,1024], glist, prot_idx [B,P,w][, psc [B,8421]]).
+    With ``psc`` present the view list is ecfp8-gconv__pcnn2d-psc (the psc net is Unsqueeze(0), :114-115).
     Returns (outputs [B,1], nonsat evaluations)."""
     v_ecfp = batch["ecfp"].unsqueeze(0)
     v_gconv, n_eval = gconv_net(batch["glist"], p, prefix="0.models.1.0.")
@@ -203,7 +204,10 @@ def dti_forward(p, batch, num_heads, n_pcnn_layers, n_lin):
     v_prot = pcnn2d(v_prot,
                     [p["0.models.2.1.lin_kernels.%d.weight" % i] for i in range(n_pcnn_layers)],
                     [p["0.models.2.1.lin_kernels.%d.bias" % i] for i in range(n_pcnn_layers)])
-    x = joint_attention([v_ecfp, v_gconv, v_prot], p, num_heads, prefix="1.")
+    views = [v_ecfp, v_gconv, v_prot]
+    if batch.get("psc") is not None:
+        views.append(batch["psc"].unsqueeze(0))
+    x = joint_attention(views, p, num_heads, prefix="1.")
     k = 2
     for _ in range(n_lin):
         x = linear(x, p["%d.weight" % k], p["%d.bias" % k])

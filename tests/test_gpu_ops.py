@@ -457,6 +457,65 @@ def test_davis_full_size_step_vs_oracle(device):
     check(["0."])
 
 
+@pytest.mark.parametrize("shape,views", [("kiba", ("pcnn2d",)), ("metz", ("pcnn2d", "psc"))])
+def test_kiba_and_metz_shaped_step_vs_oracle(device, shape, views):
+    """BASELINE.json configs 3 and 5 at full per-GPU size: KIBA-shaped pairs (drugs to 70 atoms, proteins to 376
+    segments: S up to 447 tokens) and Metz-shaped pairs with the fourth view ``psc`` ([B,8421] descriptors,
+    ecfp8-gconv__pcnn2d-psc), B = 128, tuned model, dropout off.  Index tensors bit-exact; outputs and loss against the
+    fp64 oracle with the same weights; the gradient in the L2 norm over all parameters (why not element-wise: see the
+    Davis test above), plus the embedding gradient's padding row."""
+    from jova_amd import synth
+    from jova_amd.data.collate import collate_pairs
+    from jova_amd.feat.mol_graphs import ConvMol
+    from jova_amd.train import TUNED_DAVIS_HPARAMS, Trainer, create_integrated_net
+    from oracle import mol_graphs as og
+    from oracle import nn_ref as R
+    hp = dict(TUNED_DAVIS_HPARAMS)
+    hp["dprob"] = 0.0
+    hp["prot"] = dict(hp["prot"], model_types=list(views))
+    pool = synth.SyntheticPool(shape, seed=1, n_mols=160, n_prots=96)
+    cms = [ConvMol(f, a, smiles=str(i)) for i, (f, a) in enumerate(pool.mols)]
+    torch.manual_seed(64)
+    net = create_integrated_net(hp, pool.protein_profile)
+    sd0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.to(device).train()
+    named = dict(net.named_parameters())
+    mi, pi, y, w = pool.sample_pairs(np.random.RandomState(8), 128)
+    batch = collate_pairs(pool, cms, mi, pi, y, w, device, net[0].models[2][0], with_psc="psc" in views)
+    tr = Trainer(net, hp)
+    tr.flat.zero_grad()
+    loss, out = tr.forward_loss(batch)
+    loss.backward()
+
+    torch.set_num_threads(8)
+    b = og.agglomerate([og.SortedMol(*pool.mols[i]) for i in mi])
+    gl = og.gconv_input_list(b)
+    for got, want in zip(batch.glist, gl):
+        if isinstance(want, np.ndarray):
+            assert np.array_equal(got.cpu().numpy(), want)
+    glist = [torch.from_numpy(gl[0]), torch.from_numpy(gl[1]), torch.from_numpy(gl[2]), gl[3]] + \
+            [torch.from_numpy(a) for a in gl[4:]]
+    idx = og.embedding_indices([pool.prot_names[i] for i in pi], pool.protein_profile, fill_val=pool.vocab)
+    p = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v) for k, v in sd0.items()}
+    ob = dict(ecfp=torch.from_numpy(pool.ecfp[mi]).double(), glist=glist, prot_idx=torch.from_numpy(idx),
+              psc=torch.from_numpy(pool.psc[pi]).double() if "psc" in views else None)
+    want, _ = R.dti_forward(p, ob, hp["attn_heads"], hp["prot"]["pcnn_num_layers"], len(hp["lin_dims"]))
+    wl = R.mse_loss(want, torch.from_numpy(w), torch.from_numpy(y))
+    wl.backward()
+    H.assert_close(out, want.detach(), tol=3e-4, what="outputs")
+    assert abs(loss.item() - float(wl.detach())) <= 1e-5 * abs(float(wl.detach()))
+    num = den = 0.0
+    for k, v in p.items():
+        if torch.is_tensor(v) and v.requires_grad and v.grad is not None:
+            g = v.grad.clone()
+            if k.endswith("embedding.weight"):
+                g[hp["prot"]["vocab_size"]] = 0
+                assert float(named[k].grad[hp["prot"]["vocab_size"]].abs().max()) == 0.0
+            num += float(((named[k].grad.detach().cpu().double() - g) ** 2).sum())
+            den += float((g ** 2).sum())
+    assert (num / den) ** 0.5 <= 2e-2, "end-to-end gradient L2 error %.3e" % ((num / den) ** 0.5)
+
+
 def test_config4_graph_stack_vs_oracle(device):
     """BASELINE.json config 4 at full size (4096 molecules, ~246 k atoms, degrees up to 10): conv -> BN+ReLU -> pool
     -> conv -> pool forward against the fp32 oracle on the host, plus size-independent properties of the backward:
