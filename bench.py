@@ -33,13 +33,37 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32) dense peak
 
 
+# name -> (synthetic shape, protein views, description)
+WORKLOADS = {
+    "davis": ("davis", ["pcnn2d"], "Davis DTI joint-view model (ecfp8-gconv__pcnn2d, tuned hparams) fwd+bwd+SGD, "
+                                   "B=128 per GPU, synthetic Davis-shaped batches resident in HBM"),
+    "kiba": ("kiba", ["pcnn2d"], "KIBA-shaped DTI joint-view model (ecfp8-gconv__pcnn2d, tuned hparams) fwd+bwd+SGD, "
+                                 "B=128 per GPU, synthetic KIBA-shaped batches (proteins to 376 segments) resident in HBM"),
+    "metz_psc": ("metz", ["pcnn2d", "psc"], "Metz-shaped DTI joint-view model with the PSC view "
+                                            "(ecfp8-gconv__pcnn2d-psc, tuned hparams) fwd+bwd+SGD, B=128 per GPU, "
+                                            "synthetic batches resident in HBM"),
+}
+
+
 def build_batches(pool, conv_mols, hp, device, n_batches, seed, prot2vec):
     rng = np.random.RandomState(seed)
     out = []
     for _ in range(n_batches):
         mi, pi, y, w = pool.sample_pairs(rng, hp["tr_batch_size"])
-        out.append(collate_pairs(pool, conv_mols, mi, pi, y, w, device, prot2vec))
+        out.append(collate_pairs(pool, conv_mols, mi, pi, y, w, device, prot2vec,
+                                 with_psc="psc" in hp["prot"]["model_types"]))
     return out
+
+
+def measured_traffic():
+    """HBM-side bytes per launch of the probed GEMM from the committed PMC passes (profiles/r01_pmc_ffn1.json:
+    FETCH_SIZE / WRITE_SIZE collected in separate rocprofv3 --pmc runs of tools/one_gemm.py, gfx950 corrections applied
+    as MI355X_MICROARCH.md prescribes).  It is quoted for the S = 279 launch those passes ran, not re-measured here."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_ffn1.json")) as f:
+            return int(json.load(f)["traffic_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def cpu_baseline(pool, hp, batch_ids, state_dict, n_steps, threads):
@@ -56,7 +80,8 @@ def cpu_baseline(pool, hp, batch_ids, state_dict, n_steps, threads):
             [torch.from_numpy(a) for a in gl[4:]]
     idx = og.embedding_indices([pool.prot_names[i] for i in pi], pool.protein_profile, fill_val=pool.vocab)
     t_col = time.perf_counter() - t_col
-    batch = dict(ecfp=torch.from_numpy(pool.ecfp[mi]), glist=glist, prot_idx=torch.from_numpy(idx))
+    batch = dict(ecfp=torch.from_numpy(pool.ecfp[mi]), glist=glist, prot_idx=torch.from_numpy(idx),
+                 psc=torch.from_numpy(pool.psc[pi]) if "psc" in hp["prot"]["model_types"] else None)
     p = {k: (v.detach().cpu().clone().requires_grad_(v.is_floating_point() and "running" not in k))
          for k, v in state_dict.items()}
     yt, wt = torch.from_numpy(y).float(), torch.from_numpy(w).float()
@@ -143,6 +168,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph-stress", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="davis",
+                    help="davis = BASELINE.json configs[1] (the bench line); kiba / metz_psc = configs[3] / [5] shapes")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,7 +185,9 @@ def main():
         pg = torch.distributed.group.WORLD
 
     hp = dict(TUNED_DAVIS_HPARAMS)
-    pool = synth.SyntheticPool("davis", seed=1)
+    shape, pviews, workload_text = WORKLOADS[args.workload]
+    hp["prot"] = dict(hp["prot"], model_types=list(pviews))
+    pool = synth.SyntheticPool(shape, seed=1)
     conv_mols = [ConvMol(f, a, smiles=str(i)) for i, (f, a) in enumerate(pool.mols)]
     torch.manual_seed(1)                                   # identical initial weights on every rank
     model = create_integrated_net(hp, pool.protein_profile).to(device).train()
@@ -197,16 +226,17 @@ def main():
     flops = sum(f for _, _, f in probe)
     ms = sum(a.elapsed_time(b) for a, b, _ in probe)
     tfl = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    roofline = dict(kernel="gemm_f32_kernel<K-contig,K-contig> (JointAttention FFN linear1, [S*B,512]x[512,2048]+bias+ReLU)",
+    roofline = dict(kernel="gemm_f32_fast_kernel<K-contig,K-contig> (JointAttention FFN linear1, [S*B,512]x[512,2048]+bias+ReLU)",
                     bound="mfma", achieved=round(tfl, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(tfl / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                    frac=round(tfl / MFMA_F32_PEAK_TFLOPS, 4), traffic=measured_traffic(),
+                    traffic_note="bytes per launch at S=279 (profiles/r01_pmc_ffn1.json: 2*FETCH_SIZE + WRITE_SIZE, "
+                                 "separate --pmc passes); algorithmic bytes of that launch 369.9e6",
                     launches=len(probe), avg_us=round(ms * 1e3 / max(len(probe), 1), 1))
     line = dict(metric="DTI training pairs/sec (fwd+bwd, whole node) + achieved HBM GB/s fraction",
                 value=round(pairs_per_s, 1), unit="pairs/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                 ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
                 vs_baseline=None, dtype="f32", data="synthetic",
-                config=dict(workload="Davis DTI joint-view model (ecfp8-gconv__pcnn2d, tuned hparams) fwd+bwd+SGD, "
-                                     "B=128 per GPU, synthetic Davis-shaped batches resident in HBM",
+                config=dict(workload=workload_text,
                             global_batch=bsz * world, parallelism="dp%d" % world,
                             trainable_params=count_parameters(model)),
                 final_loss=round(final_loss, 6), roofline=roofline)
