@@ -107,7 +107,7 @@ def cpu_baseline(pool, hp, batch_ids, state_dict, n_steps, threads):
                        % (n_steps, hp["tr_batch_size"], med, t_col * 1e3))
 
 
-def graph_stress(device, reps=20, full=False):
+def graph_stress(device, reps=20, full=True):
     """Config 4: 4096 molecules (~246 k atoms, degree <= 10): graph kernels against the HBM roofline."""
     from jova_amd.data.collate import process_gconv_view_data
     from jova_amd.nn.layers import GraphConvLayer, GraphPool
@@ -142,14 +142,17 @@ def graph_stress(device, reps=20, full=False):
         timed("graphconv_fwd_l2(64->64)", lambda: conv2(gl2), 4 * (n * 64 + n * 64 + e) + wbytes)
         timed("graphpool_fwd(64)", lambda: gp(gl2), 4 * (2 * n * 64 + e) + n * 64)
     if full:
-        # backward kernels: parameters get .grad buffers first so the kernels accumulate in place (as in the trainer)
-        for m in (conv1, conv2):
+        # backward kernels: parameters get .grad buffers first so the kernels accumulate in place (as in the trainer).
+        # In the model the BatchNorm behind each convolution applies the backward of the convolution's ReLU (it reads
+        # that output anyway), so the convolution's backward receives dZ: timed here with activation=None layers.
+        conv1b, conv2b = GraphConvLayer(75, 64, activation=None).to(device), GraphConvLayer(64, 64, activation=None).to(device)
+        for m in (conv1b, conv2b):
             for prm in m.parameters():
                 prm.grad = torch.zeros_like(prm)
         x2g = x2.clone().requires_grad_(True)
         gl2g = [x2g] + glist[1:]
         g64 = torch.randn(n, 64, device=device)
-        y1, y2, yp = conv1(glist), conv2(gl2g), gp(gl2g)
+        y1, y2, yp = conv1b(glist), conv2b(gl2g), gp(gl2g)
 
         def bwd(y):
             x2g.grad = None

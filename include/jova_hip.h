@@ -46,11 +46,14 @@ size_t jova_graphconv_workspace_floats(int f_in, int f_out);
 
 /* Backward of the above.  dy [N, f_out]; y = forward output when the layer applied ReLU (mask), else NULL.
  * dweight/dbias: HOST arrays of 21 device pointers, accumulate.  dx [N, f_in] (optional, fp32 atoms only) needs
- * gbuf [N, f_in] scratch and `weight`.  sym_flag: device int from jova_adj_symmetry (NULL or 0 -> atomic scatter). */
+ * gbuf [N, f_in] scratch and `weight`.  sym_flag: device int from jova_adj_symmetry (NULL or 0 -> atomic scatter).
+ * deg_slice_host: optional HOST copy of deg_slice (the collator has it: mol_graphs.py:304-314); with it the work is
+ * split on the host into equally long workgroups that are all resident at once, without it into fixed tile groups. */
 int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t ld_atoms, int64_t n_atoms, int f_in, int f_out,
                        const int64_t* deg_slice, const int32_t* const* adj, const float* const* weight,
                        const float* dy, const float* y_or_null, float* const* dweight, float* const* dbias,
-                       float* dx_or_null, float* gbuf_or_null, const int* sym_flag, void* stream);
+                       float* dx_or_null, float* gbuf_or_null, const int* sym_flag, const int64_t* deg_slice_host,
+                       void* stream);
 
 /* *flag <- 1 iff the adjacency is a simple undirected graph (no self loops / duplicates, i in nbr(j) <=> j in nbr(i)):
  * then the backward scatters above and below run as gathers.  Always true for ConvMol bond graphs. */
@@ -97,10 +100,13 @@ int jova_colstats(const float* x, int64_t n_rows, int c, double* stats, void* st
 int jova_batchnorm_fwd(const float* x, int64_t n_rows, int c, const double* stats, const float* gamma,
                        const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                        int64_t* num_batches, int relu, float* y, float* mean_rstd, void* stream);
-/* y = forward output when ReLU was fused (mask), else NULL; dgamma/dbeta accumulate; sums_ws fp64 [2,c] scratch */
+/* y = forward output when ReLU was fused (mask), else NULL; dgamma/dbeta accumulate; sums_ws fp64 [2,c] scratch.
+ * relu_input_mask != 0: x is itself a ReLU output (GraphConvLayer's built-in activation, layers.py:344-345, in front
+ * of the BatchNorm, train_joint_attn.py:157-158) and dx is zeroed where x <= 0, i.e. dx is already the gradient in
+ * front of that ReLU; the producer's backward then takes y_or_null = NULL (see jova_graphconv_bwd). */
 int jova_batchnorm_bwd(const float* x, const float* dy, const float* y_or_null, const float* mean_rstd,
-                       const float* gamma, int64_t n_rows, int c, float* dx, float* dgamma, float* dbeta,
-                       double* sums_ws, void* stream);
+                       const float* gamma, int64_t n_rows, int c, int relu_input_mask, float* dx, float* dgamma,
+                       float* dbeta, double* sums_ws, void* stream);
 /* out[c] += column sums of x [n_rows, c] (bias gradients) */
 int jova_colsum_add(const float* x, int64_t n_rows, int c, int64_t ld, float* out, void* stream);
 

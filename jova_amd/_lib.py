@@ -9,13 +9,13 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjova_hip.so")
+LIB_PATH = os.environ.get("JOVA_LIB") or os.path.join(_HERE, "libjova_hip.so")    # JOVA_LIB: instrumented dev builds
 
 # signature codes: p = pointer, i = int, q = int64, f = float, Q = uint64
 _SIGS = {
     "jova_graphconv_fwd": "piqqiipppp" + "ipppp",
     "jova_atoms_to_f32": "pqiipp",
-    "jova_graphconv_bwd": "piqqiippp" + "pppp" + "pppp",
+    "jova_graphconv_bwd": "piqqiippp" + "pppp" + "ppppp",
     "jova_adj_symmetry": "qpppp",
     "jova_graphpool_fwd": "pqipp" + "ppp",
     "jova_graphpool_bwd": "ppqipp" + "ppip",
@@ -26,7 +26,7 @@ _SIGS = {
     "jova_gemm_f32": "pqqpqqpq" + "iiif" + "ppqii" + "ii" + "qqqqqq" + "p",
     "jova_colstats": "pqipp",
     "jova_batchnorm_fwd": "pqippp" + "ff" + "ppp" + "ippp",
-    "jova_batchnorm_bwd": "ppppp" + "qi" + "ppp" + "pp",
+    "jova_batchnorm_bwd": "ppppp" + "qii" + "ppp" + "pp",
     "jova_colsum_add": "pqiqpp",
     "jova_layernorm_fwd": "pppp" + "qif" + "ppp",
     "jova_layernorm_bwd": "ppppp" + "qi" + "pppp",

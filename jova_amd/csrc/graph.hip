@@ -9,6 +9,7 @@
 #include "common.h"
 #include "jova_hip.h"
 #include <stdlib.h>
+#include <string.h>
 
 #define TM 64
 #define NB 11
@@ -755,6 +756,474 @@ graphconv_bwd_dx_kernel(int n_atoms, int f, const long long* __restrict__ deg_sl
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, LDS-DMA form
+// The fast form of the backward (fp32 rows of 64 or 80 floats, f_out = 64, everything 16-byte aligned).  A workgroup of
+// four waves owns 32-atom tiles of ONE degree bucket, as the forward does.  Per step (= tile x gather round) every row
+// it needs - the atoms' own rows, NBP neighbour rows each, their dY rows and (ReLU mask) their Y rows - is copied
+// HBM -> LDS by global_load_lds_dwordx4 with the forward's chunk swizzle (chunk c of slot s at position c ^ (s & 15)),
+// then
+//   phase 1  dW[o][k] += sum_r dZ[r][o] * A[r][k]   (A = own rows: W_self, A = neighbour sum: W_rel)
+//            the contraction runs over the tile's ATOMS: k-step rp contracts rows rp (lanes 0..31) and rp + 16 (lanes
+//            32..63), A operand dZ[row][32 ot + i], B operand A[row][32 kt + i], both plain ds_read_b32 along an LDS
+//            row (conflict free: a half-wave reads 8 whole chunks of one row; the swizzle term rp is a compile-time
+//            constant: byte offset = (lane part ^ (rp << 4)) + rp * 256).  Wave w owns output tile (ot, kt) =
+//            (w & 1, w >> 1); the accumulators stay in registers over all tiles of the workgroup, one atomic flush at
+//            the end.  Rows of 80 floats: the 16-column tail [64, 80) is a third k tile whose k-steps the two waves of
+//            an `ot` share.
+//   phase 2  (NEED_DX) [G | T] = dZ [W_rel | W_self]: wave w owns 32 of the 128 output columns, the weights of the
+//            workgroup's degree sit in registers in the permuted k order of the forward (one ds_read_b128 of dZ per
+//            four MFMAs); G -> gbuf, T -> dx; the dx kernel below then adds the neighbours' G rows.
+// What the measurements on the config-4 batch forced (tools/bench_bwd.py, in-kernel timestamps):
+//   * no branch around a DMA or around the load of its index: hipcc puts each in a block of its own and waits for
+//     vmcnt(0) in front of the first use of a loaded index there, which serialises the gather (one round trip per
+//     plane).  Indices are always loaded for all NBP planes (entries past the list repeat its last one), the DMA
+//     bodies are straight-line per plane count (a switch around them).
+//   * one MFMA code path: a switch over specialised phase-1 bodies made hipcc keep a second copy of every
+//     accumulator.  Neighbour planes that no DMA of the workgroup's degree writes are zeroed once, phase 1 always sums
+//     NBP planes; the rows past a bucket's end get their dZ zeroed in LDS.
+//   * MFMA operands are prepared one batch AHEAD of the MFMAs that read them, in registers of their own: a VALU write
+//     to a register that an MFMA in flight still reads as A/B waits for that MFMA (phase 1: 135 -> 105 cycles/MFMA).
+//   * DB: two LDS buffers; the rows of step s + 1 are requested at the top of step s, so a workgroup always has a
+//     step's worth of bytes in flight (single buffer: a workgroup alternates between waiting and computing, and the
+//     MFMA pipes idle 45 % of the time at two workgroups per CU).
+#define DWB 2          // k-steps per operand batch of phase 1
+
+#ifdef JOVA_BWD_PROFILE
+__device__ unsigned long long g_bwd_prof[4096 * 8];
+extern "C" int jova_debug_bwd_prof(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_prof), sizeof(unsigned long long) * n);
+}
+#endif
+
+// (start, size) of every bucket with ONE batch of scalar loads, then the workgroup's bucket by selects: the dependent
+// load-compare-branch chain of locate_tiles_desc costs a memory round trip per bucket (3 us of a workgroup's life).
+__device__ __forceinline__ bool locate_tiles_batch(const long long* __restrict__ deg_slice, int blk, int group, int& deg,
+                                                   long long& bstart, int& bsize, int& tile0, int& ntile) {
+    long long ds[2 * NB];
+#pragma unroll
+    for (int k = 0; k < 2 * NB; ++k) ds[k] = deg_slice[k];
+    bool found = false;
+    deg = 0; bstart = 0; bsize = 0; tile0 = 0; ntile = 0;
+#pragma unroll
+    for (int d = NB - 1; d >= 0; --d) {
+        const int size = (int)ds[2 * d + 1];
+        const int tiles = (size + GT - 1) / GT;
+        const int groups = (tiles + group - 1) / group;
+        const bool hit = !found && blk < groups;
+        if (hit) {
+            deg = d;
+            bstart = ds[2 * d];
+            bsize = size;
+            tile0 = blk * group;
+            ntile = min(group, tiles - tile0);
+        }
+        found = found || hit;
+        blk -= groups;
+    }
+    return found;
+}
+
+// Work split decided on the host when it knows the bucket sizes (deg_slice_host): workgroups of bucket d are
+// blocks [first[d], first[d] + count), each owns tpw[d] consecutive tiles, sized so that every workgroup has about
+// the same number of steps and all of them are resident at once (one prologue / flush per workgroup slot).
+struct BwdPlan {
+    int use;
+    int first[NB + 1];       // first[d] .. first[d - 1] - 1 are the blocks of bucket d (buckets in descending order)
+    int tpw[NB];
+    int start[NB];
+    int size[NB];
+};
+
+__device__ __forceinline__ bool locate_tiles_plan(const BwdPlan& pl, int blk, int& deg, long long& bstart, int& bsize,
+                                                  int& tile0, int& ntile) {
+    bool found = false;
+    deg = 0; bstart = 0; bsize = 0; tile0 = 0; ntile = 0;
+#pragma unroll
+    for (int d = NB - 1; d >= 0; --d) {
+        const int b0 = pl.first[d + 1], b1 = pl.first[d];          // first[NB] = 0
+        if (blk >= b0 && blk < b1) {
+            found = true;
+            deg = d;
+            bstart = pl.start[d];
+            bsize = pl.size[d];
+            tile0 = (blk - b0) * pl.tpw[d];
+            ntile = min(pl.tpw[d], (bsize + GT - 1) / GT - tile0);
+        }
+    }
+    return found && ntile > 0;
+}
+
+// DMA requests of one step, straight-line: own rows (XOWN), dY / Y rows (ZLOAD) and CNT neighbour planes.
+// Buffer layout (floats): [own | N_0 .. N_{NBP-1} | dY | Y (MASK)] main planes of GT x 64, then (KG > 8) the
+// [own | N_0 ..] tail planes of GT x 16.
+template <int KG, bool MASK, int NBP, bool XOWN, bool ZLOAD, int CNT>
+__device__ __forceinline__ void bwd_issue(const float* __restrict__ x, const float* __restrict__ dy,
+                                          const float* __restrict__ y, int n_atoms, int ldx, long long row0, int rows,
+                                          const int* nidx, const int* tidx, float* buf, int tid) {
+    constexpr int MAINF = GT * 64, TAILF = GT * 16;
+    float* const zmain = buf + (1 + NBP) * MAINF;
+    float* const ymain = zmain + MAINF;
+    float* const xtail = buf + (2 + NBP + (MASK ? 1 : 0)) * MAINF;
+    const int wave = tid >> 6, sub = tid >> 4, pos = tid & 15;
+    const int chunk = (pos ^ sub) << 2;                  // slot & 15 == sub
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int r = it * 16 + sub;
+        const int rc = r < rows ? r : rows - 1;
+        const int base = (it * 16 + wave * 4) * 64;
+        if (XOWN) glds16(x + (row0 + rc) * ldx + chunk, buf + base);
+        if (ZLOAD) {
+            glds16(dy + (row0 + rc) * 64 + chunk, zmain + base);
+            if (MASK) glds16(y + (row0 + rc) * 64 + chunk, ymain + base);
+        }
+#pragma unroll
+        for (int p = 0; p < CNT; ++p)
+            glds16(x + (long long)min(max(nidx[2 * p + it], 0), n_atoms - 1) * ldx + chunk,
+                   buf + (p + 1) * MAINF + base);
+    }
+    if (KG > 8 && wave < 2) {
+        const int r = tid >> 2, tp = tid & 3;
+        const int rc = r < rows ? r : rows - 1;
+        const int tchunk = 64 + ((tp ^ ((r >> 2) & 3)) << 2);
+        const int base = (wave * 16) * 16;
+        if (XOWN) glds16(x + (row0 + rc) * ldx + tchunk, xtail + base);
+#pragma unroll
+        for (int p = 0; p < CNT; ++p)
+            glds16(x + (long long)min(max(tidx[p], 0), n_atoms - 1) * ldx + tchunk, xtail + (p + 1) * TAILF + base);
+    }
+}
+
+// Raw LDS operands of DWB k-steps (always all NBP neighbour planes: unused planes hold zeros).
+template <bool MASK, int NBP>
+struct DwBatch {
+    float z[DWB], yv[DWB], xs[DWB], sn[DWB][NBP];
+    // main image: k-steps rp0 .. rp0 + DWB - 1;  TAIL: k-steps 2 (rp0 + u) + kt of the [slot][16] tail image
+    template <bool TAIL>
+    __device__ __forceinline__ void load(const char* xp, const char* zmain, const char* ymain, int rp0, int zl,
+                                         int xl) {
+        constexpr int PL = (TAIL ? GT * 16 : GT * 64) * 4;
+#pragma unroll
+        for (int u = 0; u < DWB; ++u) {
+            // TAIL: kt's share of the row offset and swizzle is folded into zl / xl by the caller
+            const int rp = TAIL ? 2 * (rp0 + u) : rp0 + u;
+            const int zo = (zl ^ (rp << 4)) + rp * 256;
+            const int xo = TAIL ? (xl ^ (((rp >> 2) & 3) << 4)) + rp * 64 : (xl ^ (rp << 4)) + rp * 256;
+            z[u] = *reinterpret_cast<const float*>(zmain + zo);
+            if (MASK) yv[u] = *reinterpret_cast<const float*>(ymain + zo);
+            xs[u] = *reinterpret_cast<const float*>(xp + xo);
+#pragma unroll
+            for (int p = 0; p < NBP; ++p) sn[u][p] = *reinterpret_cast<const float*>(xp + (p + 1) * PL + xo);
+        }
+    }
+};
+// MFMA operands of DWB k-steps, prepared one batch ahead of the MFMAs that read them.
+template <bool MASK, int NBP>
+struct DwOps {
+    float zs[DWB], zz[DWB], xs[DWB], s[DWB];
+    __device__ __forceinline__ void prep(const DwBatch<MASK, NBP>& b, bool first) {
+#pragma unroll
+        for (int u = 0; u < DWB; ++u) {
+            float v = b.z[u];
+            if (MASK) v = b.yv[u] > 0.f ? v : 0.f;
+            zz[u] = v;
+            zs[u] = first ? v : 0.f;             // later gather rounds: the own rows / db were done in round 0
+            xs[u] = b.xs[u];
+            float t = b.sn[u][0];
+#pragma unroll
+            for (int p = 1; p < NBP; ++p) t += b.sn[u][p];
+            s[u] = t;
+        }
+    }
+    template <bool TAIL>
+    __device__ __forceinline__ void mma(f32x16& a_self, f32x16& a_rel, float& db_acc) const {
+#pragma unroll
+        for (int u = 0; u < DWB; ++u) {
+            a_self = __builtin_amdgcn_mfma_f32_32x32x2f32(zs[u], xs[u], a_self, 0, 0, 0);
+            a_rel = __builtin_amdgcn_mfma_f32_32x32x2f32(zz[u], s[u], a_rel, 0, 0, 0);
+            if (!TAIL) db_acc += zs[u];
+        }
+    }
+};
+
+template <int KG, bool MASK, int NBP>
+__device__ __forceinline__ void bwd_dw_round(const float* buf, bool first, int i, int h, int ot, int kt,
+                                             f32x16& a_self, f32x16& a_rel, f32x16& t_self, f32x16& t_rel,
+                                             float& db_acc) {
+    constexpr int MAINF = GT * 64;
+    const char* xmain = reinterpret_cast<const char*>(buf);
+    const char* zmain = reinterpret_cast<const char*>(buf + (1 + NBP) * MAINF);
+    const char* ymain = reinterpret_cast<const char*>(buf + (2 + NBP) * MAINF);
+    const char* xtail = reinterpret_cast<const char*>(buf + (2 + NBP + (MASK ? 1 : 0)) * MAINF);
+    const int e4 = (i & 3) * 4;
+    const int zl = h * 4096 + ((8 * ot + (i >> 2)) << 4) + e4;
+    const int xl = h * 4096 + ((8 * kt + (i >> 2)) << 4) + e4;
+    const int zt = (zl ^ (kt << 4)) + kt * 256;
+    const int xt = h * 1024 + (((i >> 2) & 3) << 4) + e4 + kt * 64;
+    constexpr int NBM = 16 / DWB;                       // batches of the main image
+    constexpr int NBT = KG > 8 ? 8 / DWB : 0;           // batches of the tail image (this wave's share)
+    constexpr int NBATCH = NBM + NBT;
+    // software pipeline over batches: LDS reads two ahead, operand preparation one ahead of the MFMAs
+    DwBatch<MASK, NBP> raw[2];
+    DwOps<MASK, NBP> ops[2];
+    auto load = [&](DwBatch<MASK, NBP>& r, int b) {
+        if (b < NBM) r.template load<false>(xmain, zmain, ymain, b * DWB, zl, xl);
+        else r.template load<true>(xtail, zmain, ymain, (b - NBM) * DWB, zt, xt);
+    };
+    load(raw[0], 0);
+    if (NBATCH > 1) load(raw[1], 1);
+    ops[0].prep(raw[0], first);
+#pragma unroll
+    for (int b = 0; b < NBATCH; ++b) {
+        if (b + 2 < NBATCH) load(raw[b & 1], b + 2);
+        if (b + 1 < NBATCH) ops[(b + 1) & 1].prep(raw[(b + 1) & 1], first);
+        __builtin_amdgcn_sched_barrier(0);
+        if (b < NBM) ops[b & 1].template mma<false>(a_self, a_rel, db_acc);
+        else ops[b & 1].template mma<true>(t_self, t_rel, db_acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int KG, bool NEED_DX, bool MASK, int NBP, bool DB>
+__global__ void __launch_bounds__(256, 2)
+graphconv_bwd_dma_kernel(const float* __restrict__ x, int n_atoms, int ldx, int f_in,
+                         const long long* __restrict__ deg_slice, GcParams P, const float* __restrict__ dy,
+                         const float* __restrict__ y, GcGrads Gd, float* __restrict__ gbuf, float* __restrict__ dx,
+                         int group, BwdPlan plan) {
+    constexpr int MAINF = GT * 64, TAILF = GT * 16;
+    constexpr int BUFF = (2 + NBP + (MASK ? 1 : 0)) * MAINF + (KG > 8 ? (1 + NBP) * TAILF : 0);
+    __shared__ __attribute__((aligned(16))) float lds[(DB ? 2 : 1) * BUFF];
+#ifdef JOVA_BWD_PROFILE
+    const unsigned long long prof_entry = wall_clock64();
+#endif
+    int deg, tile0, ntile, bsize;
+    long long bstart;
+    if (plan.use) {
+        if (!locate_tiles_plan(plan, blockIdx.x, deg, bstart, bsize, tile0, ntile)) return;
+    } else if (!locate_tiles_batch(deg_slice, blockIdx.x, group, deg, bstart, bsize, tile0, ntile)) {
+        return;
+    }
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int ot = wave & 1, kt = wave >> 1;
+    const int w_rel = deg > 0 ? 2 * (deg - 1) : 20, w_self = deg == 0 ? 20 : 2 * (deg - 1) + 1;
+    const int sub = tid >> 4;
+    const int* adj_s = deg > 0 ? P.adj[deg - 1] : reinterpret_cast<const int*>(deg_slice);
+    const int degm1 = deg > 0 ? deg - 1 : 0;
+
+    int nidx[2 * NBP];
+    int tidx[KG > 8 ? NBP : 1];
+    auto load_idx = [&](int lrow0, int rows, int nb0) {
+#pragma unroll
+        for (int p = 0; p < NBP; ++p) {
+            const int q = min(nb0 + p, degm1);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int r = it * 16 + sub;
+                const int rc = r < rows ? r : rows - 1;
+                nidx[2 * p + it] = adj_s[(long long)(lrow0 + rc) * deg + q];
+            }
+            if (KG > 8) {
+                const int r = (tid >> 2) & 31;
+                const int rc = r < rows ? r : rows - 1;
+                tidx[p] = adj_s[(long long)(lrow0 + rc) * deg + q];
+            }
+        }
+    };
+    // step (t, rd) -> buffer b.  Round 0 brings the own rows; dY / Y come with round 0, and with every round when
+    // the buffers alternate (DB).
+    auto issue = [&](int t, int rd, int b) {
+        const int lrow0 = (tile0 + t) * GT;
+        const int rows = min(GT, bsize - lrow0);
+        const long long row0 = bstart + lrow0;
+        const int cnt = min(NBP, deg - rd * NBP);
+        float* buf = lds + b * BUFF;
+#define JOVA_IS(X_, Z_, C_) bwd_issue<KG, MASK, NBP, X_, Z_, C_>(x, dy, y, n_atoms, ldx, row0, rows, nidx, tidx, buf, tid)
+#define JOVA_IS_SW(X_, Z_)                                                                                             \
+    switch (cnt) {                                                                                                     \
+        case 1: JOVA_IS(X_, Z_, 1); break;                                                                             \
+        case 2: JOVA_IS(X_, Z_, (NBP >= 2 ? 2 : NBP)); break;                                                          \
+        case 3: JOVA_IS(X_, Z_, (NBP >= 3 ? 3 : NBP)); break;                                                          \
+        case 4: JOVA_IS(X_, Z_, (NBP >= 4 ? 4 : NBP)); break;                                                          \
+        default: JOVA_IS(X_, Z_, 0); break;                                                                            \
+    }
+        if (rd == 0) { JOVA_IS_SW(true, true) }
+        else if (DB) { JOVA_IS_SW(false, true) }
+        else { JOVA_IS_SW(false, false) }
+#undef JOVA_IS_SW
+#undef JOVA_IS
+    };
+    // neighbour planes [from, NBP) of buffer b <- 0
+    auto zero_planes = [&](int b, int from) {
+        float* buf = lds + b * BUFF;
+        for (int e = tid; e < (NBP - from) * MAINF; e += 256) buf[(1 + from) * MAINF + e] = 0.f;
+        if (KG > 8) {
+            float* xtail = buf + (2 + NBP + (MASK ? 1 : 0)) * MAINF;
+            for (int e = tid; e < (NBP - from) * TAILF; e += 256) xtail[(1 + from) * TAILF + e] = 0.f;
+        }
+    };
+
+    // One flat sequence of steps = (tile, gather round); a tile of degree d takes max(1, ceil(d / NBP)) rounds (the
+    // product is linear in the neighbour sum).
+    const int nrounds = deg > NBP ? (deg + NBP - 1) / NBP : 1;
+    const int nsteps = ntile * nrounds;
+    const int cnt_last = min(NBP, deg - (nrounds - 1) * NBP);
+    if (deg < NBP) {             // planes that no DMA of this workgroup writes hold zeros for its whole life
+        zero_planes(0, max(deg, 0));
+        if (DB) zero_planes(1, max(deg, 0));
+    }
+    load_idx(tile0 * GT, min(GT, bsize - tile0 * GT), 0);
+    issue(0, 0, 0);
+    int t1 = nrounds > 1 ? 0 : 1, rd1 = nrounds > 1 ? 1 : 0;     // step s + 1
+    if (nsteps > 1) load_idx((tile0 + t1) * GT, min(GT, bsize - (tile0 + t1) * GT), rd1 * NBP);
+
+    f32x16 a_self, a_rel, t_self, t_rel, g;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a_self[r] = a_rel[r] = t_self[r] = t_rel[r] = g[r] = 0.f;
+    float db_acc = 0.f;
+    // phase 2 weights: lane (i, h) holds W[8 g + 4 h + s][32 cb + i] of W_rel (waves 0, 1) or W_self (waves 2, 3)
+    float4 bw[NEED_DX ? 8 : 1];
+    const int col2 = 32 * (wave & 1) + i;
+    if (NEED_DX) {
+        const float* W = P.w[wave < 2 ? w_rel : w_self];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float v[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) v[s] = col2 < f_in ? W[(long long)(8 * q + 4 * h + s) * f_in + col2] : 0.f;
+            bw[q] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+#ifdef JOVA_BWD_PROFILE
+    const unsigned long long prof_loop = wall_clock64();
+    unsigned long long prof_wait = 0, prof_comp = 0;
+#endif
+
+    // request step s + 1 (its indices were fetched a step earlier), then fetch the indices of step s + 2
+    auto advance = [&](int st) {
+        if (st + 1 < nsteps) {
+            const int b1 = DB ? ((st + 1) & 1) : 0;
+            // a short last round leaves stale neighbour planes in its buffer: zero them (nobody reads that buffer now)
+            if (nrounds > 1 && cnt_last < NBP && rd1 == nrounds - 1) zero_planes(b1, cnt_last);
+            issue(t1, rd1, b1);
+            int t2 = t1, rd2 = rd1 + 1;
+            if (rd2 == nrounds) { rd2 = 0; ++t2; }
+            if (st + 2 < nsteps) load_idx((tile0 + t2) * GT, min(GT, bsize - (tile0 + t2) * GT), rd2 * NBP);
+            t1 = t2;
+            rd1 = rd2;
+        }
+    };
+
+    int t = 0, rd = 0;
+    for (int st = 0; st < nsteps; ++st) {
+        const int lrow0 = (tile0 + t) * GT;
+        const int rows = min(GT, bsize - lrow0);
+        const long long row0 = bstart + lrow0;
+        float* buf = lds + (DB ? (st & 1) : 0) * BUFF;
+        float* zmain = buf + (1 + NBP) * MAINF;
+        float* ymain = zmain + MAINF;
+        const int tn = t1, rdn = rd1;            // (t, rd) of step s + 1, before advance() moves them on
+#ifdef JOVA_BWD_PROFILE
+        const unsigned long long p0 = __builtin_readcyclecounter();
+#endif
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this step's rows landed
+        __syncthreads();                         // ... for every wave; every wave is done with the previous step
+#ifdef JOVA_BWD_PROFILE
+        const unsigned long long p1 = __builtin_readcyclecounter();
+#endif
+        if (DB) advance(st);
+        if (rows < GT) {                         // partial last tile of a bucket: the clamped rows' dZ -> 0
+            for (int e = tid; e < (GT - rows) * 64; e += 256) zmain[rows * 64 + e] = 0.f;
+            __syncthreads();
+        }
+        bwd_dw_round<KG, MASK, NBP>(buf, rd == 0, i, h, ot, kt, a_self, a_rel, t_self, t_rel, db_acc);
+        if (NEED_DX && rd == 0 && (deg > 0 || wave >= 2)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[r] = 0.f;
+#pragma unroll
+            for (int G = 0; G < 8; ++G) {
+                const int off = i * 64 + (((2 * G + h) ^ (i & 15)) << 2);
+                float4 a = *reinterpret_cast<const float4*>(zmain + off);
+                if (MASK) {
+                    const float4 yv = *reinterpret_cast<const float4*>(ymain + off);
+                    a.x = yv.x > 0.f ? a.x : 0.f; a.y = yv.y > 0.f ? a.y : 0.f;
+                    a.z = yv.z > 0.f ? a.z : 0.f; a.w = yv.w > 0.f ? a.w : 0.f;
+                }
+                g = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bw[G].x, g, 0, 0, 0);
+                g = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bw[G].y, g, 0, 0, 0);
+                g = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bw[G].z, g, 0, 0, 0);
+                g = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bw[G].w, g, 0, 0, 0);
+            }
+        }
+#ifdef JOVA_BWD_PROFILE
+        const unsigned long long p2 = __builtin_readcyclecounter();
+        prof_wait += p1 - p0;
+        prof_comp += p2 - p1;
+#endif
+        if (!DB) {
+            __syncthreads();                     // this step's LDS reads are done
+            advance(st);
+        }
+        if (NEED_DX && rd == nrounds - 1 && (deg > 0 || wave >= 2)) {
+            float* dst = (wave < 2 ? gbuf : dx) + row0 * f_in + col2;
+            if (col2 < f_in) {
+                if (rows == GT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[(long long)mfma32_row(r, lane) * f_in] = g[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = mfma32_row(r, lane);
+                        if (row < rows) dst[(long long)row * f_in] = g[r];
+                    }
+                }
+            }
+        }
+        t = tn;
+        rd = rdn;
+    }
+#ifdef JOVA_BWD_PROFILE
+    const unsigned long long prof_end = wall_clock64();
+#endif
+
+    // flush: one atomic per weight element per workgroup
+    if (kt == 0) {                               // (every wave summed dZ; the kt = 0 pair covers all 64 columns)
+        db_acc += __shfl_xor(db_acc, 32, 64);
+        if (lane < 32) {
+            atomicAdd(&Gd.db[w_self][32 * ot + i], db_acc);
+            if (deg > 0) atomicAdd(&Gd.db[w_rel][32 * ot + i], db_acc);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = 32 * ot + mfma32_row(r, lane);
+        const int k = 32 * kt + i;
+        if (k < f_in) {
+            atomicAdd(&Gd.dw[w_self][o * f_in + k], a_self[r]);
+            if (deg > 0) atomicAdd(&Gd.dw[w_rel][o * f_in + k], a_rel[r]);
+        }
+        if (KG > 8 && i < 16 && 64 + i < f_in) {
+            atomicAdd(&Gd.dw[w_self][o * f_in + 64 + i], t_self[r]);
+            if (deg > 0) atomicAdd(&Gd.dw[w_rel][o * f_in + 64 + i], t_rel[r]);
+        }
+    }
+#ifdef JOVA_BWD_PROFILE
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (tid == 64 && blockIdx.x < 4096) {
+        unsigned long long* o = g_bwd_prof + blockIdx.x * 8;
+        o[0] = prof_entry; o[1] = prof_loop; o[2] = prof_end; o[3] = wall_clock64();
+        o[4] = prof_wait; o[5] = prof_comp; o[6] = nsteps;
+        o[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+               ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+    }
+#endif
+}
+
+// dx[i] (holds T_i) += sum of the neighbours' G rows; 16 lanes per atom, float4, four neighbour rows in flight.
+// Symmetric adjacency: a gather over i's own list; otherwise the scatter with float atomics.
+__global__ void __launch_bounds__(256)
+graphconv_bwd_dx_v4_kernel(int n_atoms, int f, const long long* __restrict__ deg_slice, GcParams P,
+                           const float* __restrict__ gbuf, float* __restrict__ dx, const int* __restrict__ sym_flag);
+
 // flag <- 1 iff every neighbour list is duplicate-free, self-loop-free and i in nbr(j) whenever j in nbr(i)
 __global__ void adj_symmetry_kernel(int n_atoms, const long long* __restrict__ deg_slice, GcParams P,
                                     int* __restrict__ flag) {
@@ -981,6 +1450,45 @@ graphpool_bwd_v4_kernel(const float* __restrict__ dy, const unsigned char* __res
     }
 }
 
+__global__ void __launch_bounds__(256)
+graphconv_bwd_dx_v4_kernel(int n_atoms, int f, const long long* __restrict__ deg_slice, GcParams P,
+                           const float* __restrict__ gbuf, float* __restrict__ dx, const int* __restrict__ sym_flag) {
+    const int l16 = threadIdx.x & 15;
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (row >= n_atoms) return;
+    int deg;
+    long long lrow;
+    find_bucket(deg_slice, row, deg, lrow);
+    if (deg == 0) return;
+    const int* arow = P.adj[deg - 1] + lrow * deg;
+    if (*sym_flag != 0) {
+        for (int c = 4 * l16; c < f; c += 64) {
+            float4 acc = *reinterpret_cast<const float4*>(dx + row * f + c);
+            for (int n = 0; n < deg; n += 4) {
+                int j[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) j[u] = min(max(arow[min(n + u, deg - 1)], 0), n_atoms - 1);
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(gbuf + (long long)j[u] * f + c);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (n + u < deg) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+                }
+            }
+            *reinterpret_cast<float4*>(dx + row * f + c) = acc;
+        }
+    } else {
+        for (int c = 4 * l16; c < f; c += 64) {
+            const float4 g = *reinterpret_cast<const float4*>(gbuf + row * f + c);
+            for (int n = 0; n < deg; ++n) {
+                float* d = dx + (long long)min(max(arow[n], 0), n_atoms - 1) * f + c;
+                atomicAdd(d, g.x); atomicAdd(d + 1, g.y); atomicAdd(d + 2, g.z); atomicAdd(d + 3, g.w);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ GraphGather2D
 // out[a][b][:] = x[mol_off[b] + a][:] if a < n_b else 0   (contiguous chunks of the degree-sorted atom tensor)
 __global__ void gather2d_fwd_kernel(const float* __restrict__ x, const int* __restrict__ mol_off, int a_max, int bsz,
@@ -1098,6 +1606,18 @@ __global__ void mul_kernel(const float* __restrict__ a, const float* __restrict_
 }
 
 // ================================================================================================ C ABI
+static int g_num_cu = 0;
+static hipError_t num_cu_cached() {
+    if (g_num_cu == 0) {
+        int dev = 0, cu = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        g_num_cu = cu > 0 ? cu : 1;
+    }
+    return hipSuccess;
+}
 static int fill_params(GcParams& P, const int32_t* const* adj, const float* const* w, const float* const* b) {
     for (int i = 0; i < 10; ++i) P.adj[i] = adj ? adj[i] : nullptr;
     for (int i = 0; i < 21; ++i) {
@@ -1194,7 +1714,7 @@ extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t l
                                   int f_out, const int64_t* deg_slice, const int32_t* const* adj,
                                   const float* const* weight, const float* dy, const float* y_or_null,
                                   float* const* dweight, float* const* dbias, float* dx_or_null, float* gbuf_or_null,
-                                  const int* sym_flag, void* stream) {
+                                  const int* sym_flag, const int64_t* deg_slice_host, void* stream) {
     JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 31), "graphconv_bwd: n_atoms out of range");
     JOVA_CHECK_ARG(f_in >= 1 && f_in <= 128, "graphconv_bwd: f_in %d not in [1,128]", f_in);
     JOVA_CHECK_ARG(f_out >= 1 && f_out <= 64, "graphconv_bwd: f_out %d not in [1,64]", f_out);
@@ -1207,6 +1727,77 @@ extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t l
     fill_params(P, adj, weight, nullptr);
     GcGrads G;
     for (int i = 0; i < 21; ++i) { G.dw[i] = dweight[i]; G.db[i] = dbias[i]; }
+    const int kg = (f_in + 7) / 8;
+    const bool al16 = ((((uintptr_t)atoms) | ((uintptr_t)dy) | ((uintptr_t)y_or_null) | ((uintptr_t)dx_or_null) |
+                        ((uintptr_t)gbuf_or_null)) & 15) == 0;
+    // fast form (see graphconv_bwd_dma_kernel): whole 256-byte rows by LDS-DMA; pad columns f_in .. 8 kg - 1 must exist
+    // and hold finite values (their products are not stored)
+    if (!atoms_is_i64 && f_out == 64 && (kg == 8 || kg == 10) && ld_atoms >= 8 * kg && (ld_atoms & 3) == 0 && al16 &&
+        (!dx_or_null || (kg == 8 && (f_in & 3) == 0)) && !getenv("JOVA_GRAPHCONV_NO_DMA")) {
+        const int tiles = cdiv(n_atoms, GT);
+        int group = tiles > 2048 ? cdiv(tiles, 2000) : 1;
+        if (getenv("JOVA_BWD_GROUP")) group = atoi(getenv("JOVA_BWD_GROUP"));
+        dim3 grid(cdiv(tiles, group) + NB);
+        const bool nodb = getenv("JOVA_BWD_NODB") != nullptr;
+        const bool db = !y_or_null && !nodb;
+        const int nbp = db ? (kg == 8 ? 3 : 2) : 4;
+        BwdPlan plan;
+        memset(&plan, 0, sizeof(plan));
+        if (deg_slice_host && !getenv("JOVA_BWD_NOPLAN")) {
+            JOVA_CHECK_HIP(num_cu_cached());
+            long long steps[NB], total = 0, tl[NB];
+            for (int d = 0; d < NB; ++d) {
+                const long long st = deg_slice_host[2 * d], sz = deg_slice_host[2 * d + 1];
+                JOVA_CHECK_ARG(sz >= 0 && st >= 0 && st + sz <= n_atoms, "graphconv_bwd: deg_slice_host[%d] out of range", d);
+                tl[d] = (sz + GT - 1) / GT;
+                const int rounds = d > nbp ? (d + nbp - 1) / nbp : 1;
+                steps[d] = tl[d] * rounds;
+                total += steps[d];
+                plan.start[d] = (int)st;
+                plan.size[d] = (int)sz;
+            }
+            const long long slots = 2ll * g_num_cu > 2 * NB ? 2ll * g_num_cu - NB : NB;
+            const long long target = total > slots ? (total + slots - 1) / slots : 1;     // steps per workgroup
+            int blk = 0;
+            plan.first[NB] = 0;
+            for (int d = NB - 1; d >= 0; --d) {
+                const int rounds = d > nbp ? (d + nbp - 1) / nbp : 1;
+                long long tpw = target / rounds;
+                if (tpw < 1) tpw = 1;
+                const long long n = (tl[d] + tpw - 1) / tpw;
+                plan.tpw[d] = (int)tpw;
+                blk += (int)n;
+                plan.first[d] = blk;
+            }
+            plan.use = 1;
+            grid = dim3(blk > 0 ? blk : 1);
+        }
+#define GC_BWD_DMA(KG_, DX_, M_, NBP_, DB_)                                                                            \
+    hipLaunchKernelGGL((graphconv_bwd_dma_kernel<KG_, DX_, M_, NBP_, DB_>), grid, dim3(256), 0, s, (const float*)atoms,\
+                       (int)n_atoms, (int)ld_atoms, f_in, (const long long*)deg_slice, P, dy, y_or_null, G,            \
+                       gbuf_or_null, dx_or_null, group, plan)
+        // dZ handed in (the consumer BatchNorm applied the ReLU mask): two LDS buffers of [own, dZ, 3 (2) neighbour
+        // planes] fit two workgroups per CU; with the Y plane only the single-buffer form does
+        if (dx_or_null) {
+            if (y_or_null || nodb) { if (y_or_null) GC_BWD_DMA(8, true, true, 4, false); else GC_BWD_DMA(8, true, false, 4, false); }
+            else GC_BWD_DMA(8, true, false, 3, true);
+        } else if (kg == 8) {
+            if (y_or_null || nodb) { if (y_or_null) GC_BWD_DMA(8, false, true, 4, false); else GC_BWD_DMA(8, false, false, 4, false); }
+            else GC_BWD_DMA(8, false, false, 3, true);
+        } else {
+            if (y_or_null || nodb) { if (y_or_null) GC_BWD_DMA(10, false, true, 4, false); else GC_BWD_DMA(10, false, false, 4, false); }
+            else GC_BWD_DMA(10, false, false, 2, true);
+        }
+#undef GC_BWD_DMA
+        JOVA_CHECK_LAUNCH("graphconv_bwd_dma");
+        if (dx_or_null) {
+            JOVA_CHECK_ARG(sym_flag, "graphconv_bwd: sym_flag is null");
+            hipLaunchKernelGGL(graphconv_bwd_dx_v4_kernel, dim3(cdiv(n_atoms, 16)), dim3(256), 0, s, (int)n_atoms, f_in,
+                               (const long long*)deg_slice, P, gbuf_or_null, dx_or_null, sym_flag);
+            JOVA_CHECK_LAUNCH("graphconv_bwd_dx_v4");
+        }
+        return JOVA_OK;
+    }
     const int NT = (f_in + 31) / 32, KS = 32 * NT + 1;
     const size_t lds = sizeof(float) * (TM * 65 + 2 * TM * KS);
     const int tiles = cdiv(n_atoms, TM);
@@ -1308,19 +1899,12 @@ extern "C" size_t jova_nonsat_workspace_bytes(int64_t n) {
     return 64 + sizeof(double) * 2 * NS_MAX_BLOCKS + sizeof(float) * 2 * (size_t)(n > 0 ? n : 0);
 }
 
-static int g_num_cu = 0;
-
 extern "C" int jova_nonsat_fwd(const float* x, int64_t n, float ep, int max_iter, float* out, float* dfac,
                                int* n_eval_dev, void* workspace, void* stream) {
     JOVA_CHECK_ARG(x && out && dfac && n_eval_dev && workspace && n >= 0, "nonsat_fwd: bad argument");
     JOVA_CHECK_ARG(max_iter >= 0 && max_iter <= 100000, "nonsat_fwd: max_iter %d", max_iter);
     hipStream_t s = (hipStream_t)stream;
-    if (g_num_cu == 0) {
-        int dev = 0, cu = 0;
-        JOVA_CHECK_HIP(hipGetDevice(&dev));
-        JOVA_CHECK_HIP(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev));
-        g_num_cu = cu > 0 ? cu : 1;
-    }
+    JOVA_CHECK_HIP(num_cu_cached());
     // workspace: ctrl[16 ints] | partial[2][NS_MAX_BLOCKS] doubles | ya[n] | yb[n]
     int* ctrl = (int*)workspace;
     double* partial = (double*)((char*)workspace + 64);

@@ -120,7 +120,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                     const float* __restrict__ y, const float* __restrict__ mean_rstd,
                                     const float* __restrict__ gamma, const double* __restrict__ sums, long long n_rows,
-                                    int c, float* __restrict__ dx, float* __restrict__ dgamma,
+                                    int c, int mask_input, float* __restrict__ dx, float* __restrict__ dgamma,
                                     float* __restrict__ dbeta) {
     const long long total = n_rows * c;
     const float inv_n = 1.f / (float)n_rows;
@@ -130,9 +130,12 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
         float g = dy[e];
         if (y && !(y[e] > 0.f)) g = 0.f;
         const float rs = mean_rstd[c + col];
-        const float xhat = (x[e] - mean_rstd[col]) * rs;
+        const float xv = x[e];
+        const float xhat = (xv - mean_rstd[col]) * rs;
         const float sg = (float)sums[col], sgx = (float)sums[c + col];
-        dx[e] = gamma[col] * rs * (g - sg * inv_n - xhat * sgx * inv_n);
+        float d = gamma[col] * rs * (g - sg * inv_n - xhat * sgx * inv_n);
+        if (mask_input && !(xv > 0.f)) d = 0.f;      // x is a ReLU output: its backward rides along (dx -> dz)
+        dx[e] = d;
         if (e < c) {       // first row's threads also publish the parameter gradients (accumulating)
             dbeta[col] += sg;
             dgamma[col] += sgx;
@@ -381,8 +384,8 @@ extern "C" int jova_batchnorm_fwd(const float* x, int64_t n_rows, int c, const d
 }
 
 extern "C" int jova_batchnorm_bwd(const float* x, const float* dy, const float* y_or_null, const float* mean_rstd,
-                                  const float* gamma, int64_t n_rows, int c, float* dx, float* dgamma, float* dbeta,
-                                  double* sums_ws, void* stream) {
+                                  const float* gamma, int64_t n_rows, int c, int relu_input_mask, float* dx,
+                                  float* dgamma, float* dbeta, double* sums_ws, void* stream) {
     JOVA_CHECK_ARG(x && dy && mean_rstd && gamma && dx && dgamma && dbeta && sums_ws && n_rows >= 1 && c >= 1,
                    "batchnorm_bwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
@@ -396,7 +399,7 @@ extern "C" int jova_batchnorm_bwd(const float* x, const float* dy, const float* 
     const long long total = n_rows * c;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, x, dy, y_or_null, mean_rstd, gamma, sums_ws,
-                       (long long)n_rows, c, dx, dgamma, dbeta);
+                       (long long)n_rows, c, relu_input_mask, dx, dgamma, dbeta);
     JOVA_CHECK_LAUNCH("bn_bwd_apply");
     return JOVA_OK;
 }

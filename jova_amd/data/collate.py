@@ -51,6 +51,7 @@ def process_gconv_view_data(mols, device):
     if device.type == "cuda":
         topo = F_.Topology(deg_slice, glist[4:], n_atoms_lst, n)
         topo._mol_off = d32[o:o + len(n_atoms_lst) + 1]
+        topo._deg_slice_host = np.ascontiguousarray(mm.deg_slice, dtype=np.int64).copy()
         deg_slice._jova_topology = topo
     return glist
 

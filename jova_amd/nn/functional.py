@@ -10,6 +10,7 @@ returns ``None`` for that input; otherwise a zero tensor is allocated, filled an
 import ctypes
 import math
 
+import numpy as np
 import torch
 
 from .. import _lib
@@ -82,6 +83,7 @@ class Topology(object):
         self._mol_off = None
         self._atoms_f32 = None
         self._sym_host = None
+        self._deg_slice_host = None
 
     def atoms_f32(self, atoms):
         """fp32 copy of the batch's int64 atom features, rows zero-padded to a multiple of 16 floats (made once)."""
@@ -93,6 +95,14 @@ class Topology(object):
             call("jova_atoms_to_f32", P(atoms), n, f, ld, P(out), stream())
             self._atoms_f32 = (key, out, atoms)      # keeps `atoms` alive so the pointer key stays unique
         return self._atoms_f32[1]
+
+    @property
+    def deg_slice_host(self):
+        """Host copy of deg_slice (numpy int64 [11, 2]): handed over by the collator, which builds it on the host;
+        otherwise one device->host read per batch, cached."""
+        if self._deg_slice_host is None:
+            self._deg_slice_host = np.ascontiguousarray(self.deg_slice.cpu().numpy(), dtype=np.int64)
+        return self._deg_slice_host
 
     @property
     def symmetric(self):
@@ -161,9 +171,12 @@ class GraphConvFunction(torch.autograd.Function):
         need_dx = (not ctx.is_i64) and ctx.needs_input_grad[0]
         dx = _empty((n, f_in), out) if need_dx else None
         gbuf = _empty((n, f_in), out) if need_dx else None
+        # (a BatchNorm that consumes this layer's ReLU output applies the ReLU backward itself: mask_fused)
+        mask = ctx.relu and not getattr(ctx, "mask_fused", False)
         call("jova_graphconv_bwd", P(xf), 0, ld, n, f_in, f_out, P(topo.deg_slice), topo.adj_ptrs,
-             ptr_array(ctx.weights), P(dy), P(out) if ctx.relu else None, ptr_array(sink.targets[:21]),
-             ptr_array(sink.targets[21:]), P(dx), P(gbuf), P(topo.sym_flag), stream())
+             ptr_array(ctx.weights), P(dy), P(out) if mask else None, ptr_array(sink.targets[:21]),
+             ptr_array(sink.targets[21:]), P(dx), P(gbuf), P(topo.sym_flag),
+             ctypes.c_void_p(topo.deg_slice_host.ctypes.data), stream())
         return (dx, None, None, None) + tuple(sink.returns)
 
 
@@ -350,7 +363,8 @@ class BatchNormFunction(torch.autograd.Function):
     """nn.BatchNorm1d in training mode over [rows, C] (+ optional fused ReLU); running stats updated in-kernel."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches, eps, momentum, relu, stats):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches, eps, momentum, relu, stats,
+                input_relu=False):
         x = _c(x)
         n, c = x.shape
         if n < 2:
@@ -363,6 +377,7 @@ class BatchNormFunction(torch.autograd.Function):
         call("jova_batchnorm_fwd", P(x), n, c, P(stats), P(gamma), P(beta), float(eps), float(momentum),
              P(running_mean), P(running_var), P(num_batches), int(relu), P(y), P(mean_rstd), stream())
         ctx.relu = relu
+        ctx.input_relu = bool(input_relu)     # x is the sole-consumer output of a ReLU: its backward is fused below
         ctx.params = (gamma, beta)
         ctx.save_for_backward(x, y if relu else None, mean_rstd)
         return y
@@ -378,9 +393,9 @@ class BatchNormFunction(torch.autograd.Function):
         db = sink.targets[1] if sink.targets[1] is not None else _zeros((c,), x)
         dx = torch.empty_like(x)
         ws = _empty((2, c), x, torch.float64)
-        call("jova_batchnorm_bwd", P(x), P(dy), P(y) if ctx.relu else None, P(mean_rstd), P(gamma), n, c, P(dx), P(dg),
-             P(db), P(ws), stream())
-        return dx, sink.returns[0], sink.returns[1], None, None, None, None, None, None, None
+        call("jova_batchnorm_bwd", P(x), P(dy), P(y) if ctx.relu else None, P(mean_rstd), P(gamma), n, c,
+             int(ctx.input_relu), P(dx), P(dg), P(db), P(ws), stream())
+        return dx, sink.returns[0], sink.returns[1], None, None, None, None, None, None, None, None
 
 
 def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps, relu):

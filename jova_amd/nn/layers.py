@@ -125,7 +125,9 @@ class BatchNorm1d(nn.BatchNorm1d):
     """nn.BatchNorm1d over [rows, C] (training: batch statistics + running-stat update; eval: running statistics)."""
     fused_relu = False
 
-    def forward(self, x, stats=None):
+    def forward(self, x, stats=None, input_relu=False):
+        """``input_relu``: x is a ReLU output that only this layer consumes; the training-mode backward then also
+        applies that ReLU's backward (GraphConvSequential's conv -> BatchNorm peephole)."""
         if x.dim() != 2:
             raise ValueError("expected 2D input (got %dD input)" % x.dim())
         if self.training or not self.track_running_stats:
@@ -134,7 +136,7 @@ class BatchNorm1d(nn.BatchNorm1d):
             rv = self.running_var if self.track_running_stats else None
             nb = self.num_batches_tracked if self.track_running_stats else None
             return F_.BatchNormFunction.apply(x, self.weight, self.bias, rm, rv, nb, self.eps, mom, self.fused_relu,
-                                              stats)
+                                              stats, input_relu)
         return F_.batch_norm_eval(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                   self.fused_relu)
 

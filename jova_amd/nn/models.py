@@ -29,8 +29,9 @@ class GraphConvSequential(nn.Sequential):
     """Threads ``input[0]`` (atom features) through the modules; the topology entries stay fixed (models.py:336-349).
 
     Peephole fusions that keep results identical: a GraphConvLayer directly followed by BatchNorm1d hands it the
-    batch statistics computed in the convolution's own epilogue; BatchNorm1d directly followed by ReLU applies it
-    in the same kernel.
+    batch statistics computed in the convolution's own epilogue, and the BatchNorm backward applies the backward of
+    the convolution's built-in ReLU (it reads that output anyway), so the convolution's backward receives dZ
+    directly; BatchNorm1d directly followed by ReLU applies it in the same kernel.
     """
 
     def forward(self, input):
@@ -38,6 +39,7 @@ class GraphConvSequential(nn.Sequential):
         input = list(input[0])
         mods = list(self._modules.values())
         pending_stats = None
+        pending_relu_out = None                     # output of a ReLU-activated conv that the next BatchNorm consumes
         k = 0
         while k < len(mods):
             module = mods[k]
@@ -45,11 +47,16 @@ class GraphConvSequential(nn.Sequential):
             if isinstance(module, BatchNorm1d):
                 fuse = isinstance(nxt, nn.ReLU)
                 module.fused_relu = fuse
+                fuse_in = pending_relu_out is not None and module.training and pending_relu_out is input[0] and \
+                    getattr(input[0].grad_fn, "__class__", None).__name__ == "GraphConvFunctionBackward"
                 try:
-                    input[0] = module(input[0], pending_stats if module.training else None)
+                    input[0] = module(input[0], pending_stats if module.training else None, input_relu=fuse_in)
                 finally:
                     module.fused_relu = False
+                if fuse_in:
+                    pending_relu_out.grad_fn.mask_fused = True
                 pending_stats = None
+                pending_relu_out = None
                 if fuse:
                     k += 1                          # the ReLU ran inside the BatchNorm kernel
             elif isinstance(module, (nn.BatchNorm1d, nn.Dropout, nn.Linear, nn.ReLU, NonsatActivation)):
@@ -60,6 +67,8 @@ class GraphConvSequential(nn.Sequential):
                     (module.activation is None or isinstance(module.activation, ReLU)):
                 pending_stats = torch.empty((2, module.out_dim), dtype=torch.float64, device=input[0].device)
                 input[0] = module(input, bn_stats=pending_stats)
+                if isinstance(module.activation, ReLU):
+                    pending_relu_out = input[0]
             else:
                 input[0] = module(input)
             k += 1
