@@ -1756,17 +1756,24 @@ extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t l
                 plan.start[d] = (int)st;
                 plan.size[d] = (int)sz;
             }
-            const long long slots = 2ll * g_num_cu > 2 * NB ? 2ll * g_num_cu - NB : NB;
-            const long long target = total > slots ? (total + slots - 1) / slots : 1;     // steps per workgroup
+            // smallest step target whose workgroup count fits the chip's 2 slots per CU (all resident at once)
+            const long long slots = 2ll * g_num_cu;
+            long long target = total > slots ? (total + slots - 1) / slots : 1;
             int blk = 0;
+            for (;; ++target) {
+                blk = 0;
+                for (int d = NB - 1; d >= 0; --d) {
+                    const int rounds = d > nbp ? (d + nbp - 1) / nbp : 1;
+                    const long long tpw = target / rounds > 1 ? target / rounds : 1;
+                    plan.tpw[d] = (int)tpw;
+                    blk += (int)((tl[d] + tpw - 1) / tpw);
+                }
+                if (blk <= slots || target > total) break;
+            }
             plan.first[NB] = 0;
+            blk = 0;
             for (int d = NB - 1; d >= 0; --d) {
-                const int rounds = d > nbp ? (d + nbp - 1) / nbp : 1;
-                long long tpw = target / rounds;
-                if (tpw < 1) tpw = 1;
-                const long long n = (tl[d] + tpw - 1) / tpw;
-                plan.tpw[d] = (int)tpw;
-                blk += (int)n;
+                blk += (int)((tl[d] + plan.tpw[d] - 1) / plan.tpw[d]);
                 plan.first[d] = blk;
             }
             plan.use = 1;
