@@ -33,11 +33,12 @@ int jova_abi_version(void);
  * in linear_layers order (rel_1, self_1, ..., rel_10, self_10, self_0), weight[k] = [f_out, f_in].
  * out [N, f_out] = act( W_rel[d] . sum_nbr x + b_rel[d] + W_self[d] . x + b_self[d] ).
  * bn_stats (optional, fp64 [2, f_out]): column sum / sum of squares of `out` for the BatchNorm1d that follows.
- * packed_ws: scratch of jova_graphconv_workspace_floats(f_in, f_out) floats. */
+ * packed_ws: scratch of jova_graphconv_workspace_floats(f_in, f_out) floats.
+ * deg_slice_host: optional HOST copy of deg_slice (see jova_graphconv_bwd). */
 int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t ld_atoms, int64_t n_atoms, int f_in, int f_out,
                        const int64_t* deg_slice, const int32_t* const* adj, const float* const* weight,
                        const float* const* bias, int relu, float* out, double* bn_stats, float* packed_ws,
-                       void* stream);
+                       const int64_t* deg_slice_host, void* stream);
 /* int64 atom features [n, f] -> fp32 rows padded with zeros to ld floats (ld % 4 == 0 enables 16-byte row loads in
  * jova_graphconv_fwd / _bwd; done once per batch: the features of a batch never change) */
 int jova_atoms_to_f32(const int64_t* atoms, int64_t n_atoms, int f, int ld, float* out, void* stream);
@@ -62,12 +63,19 @@ int jova_adj_symmetry(int64_t n_atoms, const int64_t* deg_slice, const int32_t* 
 /* ---- GraphPool: jova/nn/layers.py:356-393 -------------------------------------------------------------------
  * out[i] = max(x[i], max over neighbours); ties -> first candidate (self, then adjacency order) like torch.max.
  * argmax uint8 [N, f]: 0 = self, k = k-th neighbour.  Backward: sym_flag = device flag of jova_adj_symmetry;
- * host_knows_symmetric = 1 when the caller has read that flag as 1 (selects the pure-gather kernel, no memset). */
+ * host_knows_symmetric = 1 when the caller has read that flag as 1 (selects the pure-gather kernel, no memset);
+ * rev_pos (optional, from jova_adj_reverse_pos, symmetric graphs only) spares that kernel the search of every
+ * neighbour's list. */
 int jova_graphpool_fwd(const float* x, int64_t n_atoms, int f, const int64_t* deg_slice, const int32_t* const* adj,
                        float* out, uint8_t* argmax, void* stream);
 int jova_graphpool_bwd(const float* dy, const uint8_t* argmax, int64_t n_atoms, int f, const int64_t* deg_slice,
                        const int32_t* const* adj, float* dx, const int* sym_flag, int host_knows_symmetric,
-                       void* stream);
+                       const uint8_t* rev_pos_or_null, void* stream);
+/* rev_pos uint8 [sum_d n_d * d] (laid out like adj_1 | adj_2 | .. | adj_10): for atom i's n-th neighbour j the 1-based
+ * position of i in j's own list, 0xFF if absent.  A property of the batch graph (mol_graphs.py:340-378 builds both
+ * directions of every bond); built once per batch. */
+int jova_adj_reverse_pos(int64_t n_atoms, const int64_t* deg_slice, const int32_t* const* adj, uint8_t* rev_pos,
+                         void* stream);
 
 /* ---- GraphGather2D: jova/nn/layers.py:427-437 ---------------------------------------------------------------
  * mol_off int32 [batch+1] = prefix sums of n_atoms_lst; out [a_max, batch, g] = zero-padded contiguous chunks. */

@@ -13,12 +13,13 @@ LIB_PATH = os.environ.get("JOVA_LIB") or os.path.join(_HERE, "libjova_hip.so")  
 
 # signature codes: p = pointer, i = int, q = int64, f = float, Q = uint64
 _SIGS = {
-    "jova_graphconv_fwd": "piqqiipppp" + "ipppp",
+    "jova_graphconv_fwd": "piqqiipppp" + "ippppp",
     "jova_atoms_to_f32": "pqiipp",
     "jova_graphconv_bwd": "piqqiippp" + "pppp" + "ppppp",
     "jova_adj_symmetry": "qpppp",
     "jova_graphpool_fwd": "pqipp" + "ppp",
-    "jova_graphpool_bwd": "ppqipp" + "ppip",
+    "jova_graphpool_bwd": "ppqipp" + "ppipp",
+    "jova_adj_reverse_pos": "qpppp",
     "jova_gather2d_fwd": "ppiiipp",
     "jova_gather2d_bwd": "ppiiipp",
     "jova_nonsat_fwd": "pqfipppp" + "p",

@@ -1218,6 +1218,213 @@ graphconv_bwd_dma_kernel(const float* __restrict__ x, int n_atoms, int ldx, int 
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ forward, 4-wave form
+// Same skeleton as the backward above (flat steps over (tile, gather round), branch-free index loads and DMA bodies,
+// zero-filled unused planes, host work plan), for the forward product of a 32-atom tile:
+//   out[32][64 cols of this blockIdx.y] = X W_self^T + S W_rel^T        (K = 2 x 8 KG features)
+// Wave w owns output columns 32 (w & 1) .. +31 and HALF of the contraction (feature groups [kh KG/2, (kh+1) KG/2) of
+// both operands, kh = w >> 1), so all four waves have the same MFMA count and LDS traffic; the kh = 1 waves hand
+// their partial tile over through the (otherwise unused) dY plane of the buffer and the kh = 0 waves add it, apply
+// bias / ReLU, store and collect the BatchNorm statistics.  A fragments: one ds_read_b128 per plane per four MFMAs in
+// the permuted k order of graphconv_pack_dma_kernel; operands are summed / prepared one group ahead of their MFMAs.
+template <int KG>
+__global__ void __launch_bounds__(256, (KG > 8 ? 2 : 3))
+graphconv_fwd_dma4_kernel(const float* __restrict__ x, int n_atoms, int ldx, int f_out,
+                          const long long* __restrict__ deg_slice, GcParams P, const float* __restrict__ wq, int ncb,
+                          int relu, float* __restrict__ out, double* __restrict__ stats, int group, BwdPlan plan) {
+    constexpr int NBP = 4;
+    constexpr int HG = KG / 2;                   // feature groups (of 8) per wave
+    constexpr int MAINF = GT * 64, TAILF = GT * 16;
+    constexpr int BUFF = (2 + NBP) * MAINF + (KG > 8 ? (1 + NBP) * TAILF : 0);
+    __shared__ __attribute__((aligned(16))) float lds[BUFF];
+    float* const stage = lds + (1 + NBP) * MAINF;        // [2 column tiles][16 regs][64 lanes]
+    float* const xtail = lds + (2 + NBP) * MAINF;
+    int deg, tile0, ntile, bsize;
+    long long bstart;
+    if (plan.use) {
+        if (!locate_tiles_plan(plan, blockIdx.x, deg, bstart, bsize, tile0, ntile)) return;
+    } else if (!locate_tiles_batch(deg_slice, blockIdx.x, group, deg, bstart, bsize, tile0, ntile)) {
+        return;
+    }
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int ct = wave & 1, kh = wave >> 1;
+    const int cb = blockIdx.y * 2 + ct;
+    const int col = 32 * cb + i;
+    const bool colok = col < f_out && cb < ncb;
+    const int cbc = cb < ncb ? cb : ncb - 1;
+    const int w_rel = deg > 0 ? 2 * (deg - 1) : 20, w_self = deg == 0 ? 20 : 2 * (deg - 1) + 1;
+    const int sub = tid >> 4;
+    const int* adj_s = deg > 0 ? P.adj[deg - 1] : reinterpret_cast<const int*>(deg_slice);
+    const int degm1 = deg > 0 ? deg - 1 : 0;
+
+    int nidx[2 * NBP];
+    int tidx[KG > 8 ? NBP : 1];
+    auto load_idx = [&](int lrow0, int rows, int nb0) {
+#pragma unroll
+        for (int p = 0; p < NBP; ++p) {
+            const int q = min(nb0 + p, degm1);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int r = it * 16 + sub;
+                const int rc = r < rows ? r : rows - 1;
+                nidx[2 * p + it] = adj_s[(long long)(lrow0 + rc) * deg + q];
+            }
+            if (KG > 8) {
+                const int r = (tid >> 2) & 31;
+                const int rc = r < rows ? r : rows - 1;
+                tidx[p] = adj_s[(long long)(lrow0 + rc) * deg + q];
+            }
+        }
+    };
+    auto issue = [&](int t, int rd) {
+        const int lrow0 = (tile0 + t) * GT;
+        const int rows = min(GT, bsize - lrow0);
+        const long long row0 = bstart + lrow0;
+        const int cnt = min(NBP, deg - rd * NBP);
+#define JOVA_IS(X_, C_) bwd_issue<KG, false, NBP, X_, false, C_>(x, nullptr, nullptr, n_atoms, ldx, row0, rows, nidx, tidx, lds, tid)
+#define JOVA_IS_SW(X_)                                                                                                 \
+    switch (cnt) {                                                                                                     \
+        case 1: JOVA_IS(X_, 1); break;                                                                                 \
+        case 2: JOVA_IS(X_, 2); break;                                                                                 \
+        case 3: JOVA_IS(X_, 3); break;                                                                                 \
+        case 4: JOVA_IS(X_, 4); break;                                                                                 \
+        default: JOVA_IS(X_, 0); break;                                                                                \
+    }
+        if (rd == 0) { JOVA_IS_SW(true) } else { JOVA_IS_SW(false) }
+#undef JOVA_IS_SW
+#undef JOVA_IS
+    };
+    auto zero_planes = [&](int from) {
+        for (int e = tid; e < (NBP - from) * MAINF; e += 256) lds[(1 + from) * MAINF + e] = 0.f;
+        if (KG > 8)
+            for (int e = tid; e < (NBP - from) * TAILF; e += 256) xtail[(1 + from) * TAILF + e] = 0.f;
+    };
+
+    const int nrounds = deg > NBP ? (deg + NBP - 1) / NBP : 1;
+    const int nsteps = ntile * nrounds;
+    const int cnt_last = min(NBP, deg - (nrounds - 1) * NBP);
+    if (deg < NBP) zero_planes(max(deg, 0));
+    load_idx(tile0 * GT, min(GT, bsize - tile0 * GT), 0);
+    issue(0, 0);
+    int t1 = nrounds > 1 ? 0 : 1, rd1 = nrounds > 1 ? 1 : 0;     // step s + 1
+    if (nsteps > 1) load_idx((tile0 + t1) * GT, min(GT, bsize - (tile0 + t1) * GT), rd1 * NBP);
+
+    // B fragments of this wave's half of the contraction
+    float4 bself[HG], brel[HG];
+    {
+        const float4* ws = reinterpret_cast<const float4*>(wq) + (((long long)w_self * ncb + cbc) * KG + kh * HG) * 64 + lane;
+        const float4* wr = reinterpret_cast<const float4*>(wq) + (((long long)w_rel * ncb + cbc) * KG + kh * HG) * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < HG; ++g) {
+            bself[g] = ws[g * 64];
+            brel[g] = wr[g * 64];
+        }
+    }
+    float bias = 0.f;
+    if (colok) {
+        bias = P.b[w_self][col];
+        if (deg > 0) bias += P.b[w_rel][col];
+    }
+    double s = 0.0, q = 0.0;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    // fragment of feature group G (absolute) of plane p for atom i: main image G < 8, tail image G = 8, 9
+    // (an address select, not a branch: G is wave-uniform but only known at run time)
+    auto frag = [&](int p, int G) -> float4 {
+        const int om = p * MAINF + i * 64 + (((2 * G + h) ^ (i & 15)) << 2);
+        const int ot = (2 + NBP) * MAINF + p * TAILF + i * 16 + (((2 * (G - 8) + h) ^ ((i >> 2) & 3)) << 2);
+        return *reinterpret_cast<const float4*>(lds + ((KG == 8 || G < 8) ? om : ot));
+    };
+
+    int t = 0, rd = 0;
+    for (int st = 0; st < nsteps; ++st) {
+        const int lrow0 = (tile0 + t) * GT;
+        const int rows = min(GT, bsize - lrow0);
+        const long long row0 = bstart + lrow0;
+        const bool first = rd == 0, last = rd == nrounds - 1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this step's rows landed
+        __syncthreads();                         // ... for every wave; the hand-over area of the last tile is free
+        // operands one group ahead of their MFMAs (see the backward): raw fragments two ahead
+        float4 rx[2], rn[2][NBP], ox[2], os[2];
+        auto load = [&](int b, int g) {
+            const int G = kh * HG + g;
+            rx[b] = frag(0, G);
+#pragma unroll
+            for (int p = 0; p < NBP; ++p) rn[b][p] = frag(1 + p, G);
+        };
+        auto prep = [&](int b) {
+            float4 v = rx[b];
+            if (!first) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            ox[b] = v;
+            float4 a = rn[b][0];
+#pragma unroll
+            for (int p = 1; p < NBP; ++p) { a.x += rn[b][p].x; a.y += rn[b][p].y; a.z += rn[b][p].z; a.w += rn[b][p].w; }
+            os[b] = a;
+        };
+        load(0, 0);
+        if (HG > 1) load(1, 1);
+        prep(0);
+#pragma unroll
+        for (int g = 0; g < HG; ++g) {
+            const int b = g & 1;
+            const float4 cx = ox[b], cs = os[b];
+            if (g + 1 < HG) prep(b ^ 1);
+            if (g + 2 < HG) load(b, g + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cx.x, bself[g].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cs.x, brel[g].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cx.y, bself[g].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cs.y, brel[g].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cx.z, bself[g].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cs.z, brel[g].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cx.w, bself[g].w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cs.w, brel[g].w, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (last && kh == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[(ct * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();                         // this step's plane reads are done; the partial tiles are handed over
+        if (st + 1 < nsteps) {
+            if (nrounds > 1 && cnt_last < NBP && rd1 == nrounds - 1) zero_planes(cnt_last);
+            issue(t1, rd1);
+            int t2 = t1, rd2 = rd1 + 1;
+            if (rd2 == nrounds) { rd2 = 0; ++t2; }
+            if (st + 2 < nsteps) load_idx((tile0 + t2) * GT, min(GT, bsize - (tile0 + t2) * GT), rd2 * NBP);
+            t = t1; rd = rd1; t1 = t2; rd1 = rd2;
+        }
+        if (last) {
+            if (kh == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mfma32_row(r, lane);
+                    float v = acc[r] + stage[(ct * 16 + r) * 64 + lane] + bias;
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (row < rows && colok) {
+                        out[(row0 + row) * f_out + col] = v;
+                        s += (double)v;
+                        q += (double)v * (double)v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        }
+    }
+    if (stats && kh == 0) {
+        s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (lane < 32 && colok) {
+            atomicAdd(&stats[col], s);
+            atomicAdd(&stats[f_out + col], q);
+        }
+    }
+}
+
 // dx[i] (holds T_i) += sum of the neighbours' G rows; 16 lanes per atom, float4, four neighbour rows in flight.
 // Symmetric adjacency: a gather over i's own list; otherwise the scatter with float atomics.
 __global__ void __launch_bounds__(256)
@@ -1450,6 +1657,102 @@ graphpool_bwd_v4_kernel(const float* __restrict__ dy, const unsigned char* __res
     }
 }
 
+// bucket of `row` plus the offset of its adjacency row inside the concatenation adj_1 | adj_2 | .. | adj_10
+__device__ __forceinline__ void find_bucket_off(const long long* __restrict__ deg_slice, long long row, int& deg,
+                                                long long& lrow, long long& eoff) {
+    deg = 0;
+    lrow = 0;
+    eoff = 0;
+    long long run = 0;
+#pragma unroll
+    for (int d = 0; d < NB; ++d) {
+        const long long s = deg_slice[2 * d], c = deg_slice[2 * d + 1];
+        if (row >= s && row < s + c) { deg = d; lrow = row - s; eoff = run + (row - s) * d; }
+        run += c * d;
+    }
+}
+
+// rev_pos[e] for edge e = (atom i, its n-th neighbour j): the 1-based position of i inside j's own list (0xFF: not
+// there).  A property of the batch graph, built once per batch; with it the backward of GraphPool is a plain gather.
+__global__ void __launch_bounds__(256)
+adj_reverse_pos_kernel(int n_atoms, const long long* __restrict__ deg_slice, GcParams P,
+                       unsigned char* __restrict__ rev_pos) {
+    const int l16 = threadIdx.x & 15;
+    const int grp = (threadIdx.x & 63) >> 4;
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool rok = row < n_atoms;
+    int deg = 0;
+    long long lrow = 0, eoff = 0;
+    if (rok) find_bucket_off(deg_slice, row, deg, lrow, eoff);
+    const int* arow = deg > 0 ? P.adj[deg - 1] + lrow * deg : nullptr;
+    unsigned mine = 0xFFu;
+#pragma unroll
+    for (int n = 0; n < 10; ++n) {
+        int hit = 0;
+        if (n < deg) {
+            const int j = min(max(arow[n], 0), n_atoms - 1);
+            int dj;
+            long long lj;
+            find_bucket(deg_slice, j, dj, lj);
+            if (l16 < dj) hit = P.adj[dj - 1][lj * dj + l16] == (int)row;
+        }
+        const unsigned long long b = __ballot(hit);
+        const unsigned m16 = (unsigned)(b >> (16 * grp)) & 0xFFFFu;
+        if (l16 == n) mine = m16 ? (unsigned)__ffs(m16) : 0xFFu;
+    }
+    if (rok && l16 < deg) rev_pos[eoff + l16] = (unsigned char)mine;
+}
+
+// GraphPool backward as a gather with the precomputed reverse positions: 16 lanes per atom, float4, the (arg, dy)
+// rows of four neighbours in flight together.
+__global__ void __launch_bounds__(256)
+graphpool_bwd_v5_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg, int n_atoms, int f,
+                        const long long* __restrict__ deg_slice, GcParams P,
+                        const unsigned char* __restrict__ rev_pos, float* __restrict__ dx) {
+    const int l16 = threadIdx.x & 15;
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (row >= n_atoms) return;
+    int deg;
+    long long lrow, eoff;
+    find_bucket_off(deg_slice, row, deg, lrow, eoff);
+    const int* arow = deg > 0 ? P.adj[deg - 1] + lrow * deg : nullptr;
+    const unsigned char* prow = rev_pos + eoff;
+    for (int c = 4 * l16; c < f; c += 64) {
+        const unsigned a0 = *reinterpret_cast<const unsigned*>(arg + row * f + c);
+        const float4 g0 = *reinterpret_cast<const float4*>(dy + row * f + c);
+        float4 s;
+        s.x = (a0 & 0xFF) == 0 ? g0.x : 0.f;
+        s.y = ((a0 >> 8) & 0xFF) == 0 ? g0.y : 0.f;
+        s.z = ((a0 >> 16) & 0xFF) == 0 ? g0.z : 0.f;
+        s.w = (a0 >> 24) == 0 ? g0.w : 0.f;
+        for (int n = 0; n < deg; n += 4) {
+            long long j[4];
+            unsigned p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int nn = min(n + u, deg - 1);
+                j[u] = min(max(arow[nn], 0), n_atoms - 1);
+                p[u] = n + u < deg ? (unsigned)prow[nn] : 0x100u;      // 0x100 matches no arg-max code
+            }
+            unsigned a[4];
+            float4 g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = *reinterpret_cast<const unsigned*>(arg + j[u] * f + c);
+                g[u] = *reinterpret_cast<const float4*>(dy + j[u] * f + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s.x += (a[u] & 0xFF) == p[u] ? g[u].x : 0.f;
+                s.y += ((a[u] >> 8) & 0xFF) == p[u] ? g[u].y : 0.f;
+                s.z += ((a[u] >> 16) & 0xFF) == p[u] ? g[u].z : 0.f;
+                s.w += (a[u] >> 24) == p[u] ? g[u].w : 0.f;
+            }
+        }
+        *reinterpret_cast<float4*>(dx + row * f + c) = s;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 graphconv_bwd_dx_v4_kernel(int n_atoms, int f, const long long* __restrict__ deg_slice, GcParams P,
                            const float* __restrict__ gbuf, float* __restrict__ dx, const int* __restrict__ sym_flag) {
@@ -1627,6 +1930,47 @@ static int fill_params(GcParams& P, const int32_t* const* adj, const float* cons
     return 0;
 }
 
+// Host work plan of the 32-atom-tile kernels (see BwdPlan): buckets in descending degree, every workgroup about the
+// same number of steps (a tile of degree d takes max(1, ceil(d / nbp)) gather rounds), at most slots_per_cu x #CU
+// workgroups so that all are resident at once.  Returns the number of blocks, or -1 with the error set.
+static int make_plan(const int64_t* dsh, int64_t n_atoms, int nbp, int slots_per_cu, BwdPlan& plan) {
+    memset(&plan, 0, sizeof(plan));
+    if (num_cu_cached() != hipSuccess) { jova_set_error("make_plan: cannot query the device"); return -1; }
+    long long total = 0, tl[NB];
+    int rounds[NB];
+    for (int d = 0; d < NB; ++d) {
+        const long long st = dsh[2 * d], sz = dsh[2 * d + 1];
+        if (sz < 0 || st < 0 || st + sz > n_atoms) {
+            jova_set_error("deg_slice_host[%d] = (%lld, %lld) out of range for %lld atoms", d, st, sz, (long long)n_atoms);
+            return -1;
+        }
+        tl[d] = (sz + GT - 1) / GT;
+        rounds[d] = d > nbp ? (d + nbp - 1) / nbp : 1;
+        total += tl[d] * rounds[d];
+        plan.start[d] = (int)st;
+        plan.size[d] = (int)sz;
+    }
+    const long long slots = (long long)slots_per_cu * g_num_cu;
+    long long target = total > slots ? (total + slots - 1) / slots : 1;      // steps per workgroup
+    for (;; ++target) {
+        long long blk = 0;
+        for (int d = NB - 1; d >= 0; --d) {
+            const long long tpw = target / rounds[d] > 1 ? target / rounds[d] : 1;
+            plan.tpw[d] = (int)tpw;
+            blk += (tl[d] + tpw - 1) / tpw;
+        }
+        if (blk <= slots || target > total) break;
+    }
+    int blk = 0;
+    plan.first[NB] = 0;
+    for (int d = NB - 1; d >= 0; --d) {
+        blk += (int)((tl[d] + plan.tpw[d] - 1) / plan.tpw[d]);
+        plan.first[d] = blk;
+    }
+    plan.use = 1;
+    return blk > 0 ? blk : 1;
+}
+
 extern "C" size_t jova_graphconv_workspace_floats(int f_in, int f_out) {
     const int kh = (f_in + 1) / 2, ncb = (f_out + 31) / 32, kg = (f_in + 7) / 8;
     const size_t a = (size_t)21 * kh * ncb * 64, b = (size_t)21 * ncb * kg * 256;
@@ -1647,7 +1991,7 @@ extern "C" int jova_atoms_to_f32(const int64_t* atoms, int64_t n_atoms, int f, i
 extern "C" int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t ld_atoms, int64_t n_atoms, int f_in, int f_out,
                                   const int64_t* deg_slice, const int32_t* const* adj, const float* const* weight,
                                   const float* const* bias, int relu, float* out, double* bn_stats,
-                                  float* packed_ws, void* stream) {
+                                  float* packed_ws, const int64_t* deg_slice_host, void* stream) {
     JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 31), "graphconv_fwd: n_atoms %lld out of range", (long long)n_atoms);
     JOVA_CHECK_ARG(f_in >= 1 && f_in <= 128, "graphconv_fwd: f_in %d not in [1,128]", f_in);
     JOVA_CHECK_ARG(f_out >= 1, "graphconv_fwd: f_out %d", f_out);
@@ -1670,6 +2014,28 @@ extern "C" int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t l
                            packed_ws);
         JOVA_CHECK_LAUNCH("graphconv_pack_dma");
         const int tiles = cdiv(n_atoms, GT);
+        if (!getenv("JOVA_GRAPHCONV_OLD_FWD")) {
+            // 4-wave form; work split on the host when it knows the bucket sizes
+            BwdPlan plan;
+            memset(&plan, 0, sizeof(plan));
+            int group4 = tiles > 2048 ? cdiv(tiles, 2000) : 1;
+            dim3 grid4(cdiv(tiles, group4) + NB, cdiv(f_out, 64));
+            if (deg_slice_host) {
+                const int nblk = make_plan(deg_slice_host, n_atoms, 4, kg == 8 ? 3 : 2, plan);
+                if (nblk < 0) return JOVA_ERR_ARG;
+                grid4.x = nblk;
+            }
+            if (kg == 8)
+                hipLaunchKernelGGL((graphconv_fwd_dma4_kernel<8>), grid4, dim3(256), 0, s, (const float*)atoms,
+                                   (int)n_atoms, (int)ld_atoms, f_out, (const long long*)deg_slice, P, packed_ws, ncb,
+                                   relu, out, bn_stats, group4, plan);
+            else
+                hipLaunchKernelGGL((graphconv_fwd_dma4_kernel<10>), grid4, dim3(256), 0, s, (const float*)atoms,
+                                   (int)n_atoms, (int)ld_atoms, f_out, (const long long*)deg_slice, P, packed_ws, ncb,
+                                   relu, out, bn_stats, group4, plan);
+            JOVA_CHECK_LAUNCH("graphconv_fwd_dma4");
+            return JOVA_OK;
+        }
         const int group = tiles > 2048 ? 4 : (tiles > 512 ? 2 : 1);
         dim3 grid(cdiv(tiles, group) + NB, cdiv(f_out, 64));
         static int npl_env = -1;
@@ -1738,46 +2104,18 @@ extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t l
         int group = tiles > 2048 ? cdiv(tiles, 2000) : 1;
         if (getenv("JOVA_BWD_GROUP")) group = atoi(getenv("JOVA_BWD_GROUP"));
         dim3 grid(cdiv(tiles, group) + NB);
-        const bool nodb = getenv("JOVA_BWD_NODB") != nullptr;
+        // Two LDS buffers (JOVA_BWD_DB=1, only without the Y plane) measured no faster than one on the config-4 batch
+        // once the work plan was in (119 vs 117 us at 64 -> 64; 167 vs 128 us at 75 -> 64, where two buffers leave room
+        // for two neighbour planes only): with two workgroups per CU one computes while the other gathers.
+        const bool nodb = getenv("JOVA_BWD_DB") == nullptr;
         const bool db = !y_or_null && !nodb;
         const int nbp = db ? (kg == 8 ? 3 : 2) : 4;
         BwdPlan plan;
         memset(&plan, 0, sizeof(plan));
         if (deg_slice_host && !getenv("JOVA_BWD_NOPLAN")) {
-            JOVA_CHECK_HIP(num_cu_cached());
-            long long steps[NB], total = 0, tl[NB];
-            for (int d = 0; d < NB; ++d) {
-                const long long st = deg_slice_host[2 * d], sz = deg_slice_host[2 * d + 1];
-                JOVA_CHECK_ARG(sz >= 0 && st >= 0 && st + sz <= n_atoms, "graphconv_bwd: deg_slice_host[%d] out of range", d);
-                tl[d] = (sz + GT - 1) / GT;
-                const int rounds = d > nbp ? (d + nbp - 1) / nbp : 1;
-                steps[d] = tl[d] * rounds;
-                total += steps[d];
-                plan.start[d] = (int)st;
-                plan.size[d] = (int)sz;
-            }
-            // smallest step target whose workgroup count fits the chip's 2 slots per CU (all resident at once)
-            const long long slots = 2ll * g_num_cu;
-            long long target = total > slots ? (total + slots - 1) / slots : 1;
-            int blk = 0;
-            for (;; ++target) {
-                blk = 0;
-                for (int d = NB - 1; d >= 0; --d) {
-                    const int rounds = d > nbp ? (d + nbp - 1) / nbp : 1;
-                    const long long tpw = target / rounds > 1 ? target / rounds : 1;
-                    plan.tpw[d] = (int)tpw;
-                    blk += (int)((tl[d] + tpw - 1) / tpw);
-                }
-                if (blk <= slots || target > total) break;
-            }
-            plan.first[NB] = 0;
-            blk = 0;
-            for (int d = NB - 1; d >= 0; --d) {
-                blk += (int)((tl[d] + plan.tpw[d] - 1) / plan.tpw[d]);
-                plan.first[d] = blk;
-            }
-            plan.use = 1;
-            grid = dim3(blk > 0 ? blk : 1);
+            const int nblk = make_plan(deg_slice_host, n_atoms, nbp, 2, plan);
+            if (nblk < 0) return JOVA_ERR_ARG;
+            grid = dim3(nblk);
         }
 #define GC_BWD_DMA(KG_, DX_, M_, NBP_, DB_)                                                                            \
     hipLaunchKernelGGL((graphconv_bwd_dma_kernel<KG_, DX_, M_, NBP_, DB_>), grid, dim3(256), 0, s, (const float*)atoms,\
@@ -1839,6 +2177,19 @@ extern "C" int jova_adj_symmetry(int64_t n_atoms, const int64_t* deg_slice, cons
     return JOVA_OK;
 }
 
+extern "C" int jova_adj_reverse_pos(int64_t n_atoms, const int64_t* deg_slice, const int32_t* const* adj,
+                                    uint8_t* rev_pos, void* stream) {
+    JOVA_CHECK_ARG(deg_slice && adj && rev_pos, "adj_reverse_pos: null pointer");
+    JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 31), "adj_reverse_pos: n_atoms out of range");
+    if (n_atoms == 0) return JOVA_OK;
+    GcParams P;
+    fill_params(P, adj, nullptr, nullptr);
+    hipLaunchKernelGGL(adj_reverse_pos_kernel, dim3(cdiv(n_atoms, 16)), dim3(256), 0, (hipStream_t)stream, (int)n_atoms,
+                       (const long long*)deg_slice, P, rev_pos);
+    JOVA_CHECK_LAUNCH("adj_reverse_pos");
+    return JOVA_OK;
+}
+
 extern "C" int jova_graphpool_fwd(const float* x, int64_t n_atoms, int f, const int64_t* deg_slice,
                                   const int32_t* const* adj, float* out, uint8_t* argmax, void* stream) {
     JOVA_CHECK_ARG(x && deg_slice && adj && out && argmax, "graphpool_fwd: null pointer");
@@ -1858,7 +2209,7 @@ extern "C" int jova_graphpool_fwd(const float* x, int64_t n_atoms, int f, const 
 
 extern "C" int jova_graphpool_bwd(const float* dy, const uint8_t* argmax, int64_t n_atoms, int f,
                                   const int64_t* deg_slice, const int32_t* const* adj, float* dx, const int* sym_flag,
-                                  int sym_flag_host_hint, void* stream) {
+                                  int sym_flag_host_hint, const uint8_t* rev_pos_or_null, void* stream) {
     JOVA_CHECK_ARG(dy && argmax && deg_slice && adj && dx, "graphpool_bwd: null pointer");
     JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 31) && f >= 1, "graphpool_bwd: bad shape");
     if (n_atoms == 0) return JOVA_OK;
@@ -1867,6 +2218,12 @@ extern "C" int jova_graphpool_bwd(const float* dy, const uint8_t* argmax, int64_
     fill_params(P, adj, nullptr, nullptr);
     // the caller may vouch for a symmetric adjacency (it read the flag once per batch): 16-lanes-per-row gather form
     if (sym_flag_host_hint == 1 && (f & 3) == 0 && ((((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)argmax)) & 15) == 0) {
+        if (rev_pos_or_null) {
+            hipLaunchKernelGGL(graphpool_bwd_v5_kernel, dim3(cdiv(n_atoms, 16)), dim3(256), 0, s, dy, argmax,
+                               (int)n_atoms, f, (const long long*)deg_slice, P, rev_pos_or_null, dx);
+            JOVA_CHECK_LAUNCH("graphpool_bwd_v5");
+            return JOVA_OK;
+        }
         hipLaunchKernelGGL(graphpool_bwd_v4_kernel, dim3(cdiv(n_atoms, 16)), dim3(256), 0, s, dy, argmax,
                            (int)n_atoms, f, (const long long*)deg_slice, P, dx);
         JOVA_CHECK_LAUNCH("graphpool_bwd_v4");

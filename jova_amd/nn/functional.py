@@ -84,6 +84,7 @@ class Topology(object):
         self._atoms_f32 = None
         self._sym_host = None
         self._deg_slice_host = None
+        self._rev_pos = None
 
     def atoms_f32(self, atoms):
         """fp32 copy of the batch's int64 atom features, rows zero-padded to a multiple of 16 floats (made once)."""
@@ -95,6 +96,16 @@ class Topology(object):
             call("jova_atoms_to_f32", P(atoms), n, f, ld, P(out), stream())
             self._atoms_f32 = (key, out, atoms)      # keeps `atoms` alive so the pointer key stays unique
         return self._atoms_f32[1]
+
+    @property
+    def rev_pos(self):
+        """uint8 per directed edge: position of the source atom in its neighbour's list (symmetric graphs; once per
+        batch).  None when the adjacency is not symmetric."""
+        if self._rev_pos is None and self.symmetric:
+            n_edges = sum(int(a.numel()) for a in self.adj)
+            self._rev_pos = torch.empty(max(n_edges, 1), dtype=torch.uint8, device=self.deg_slice.device)
+            call("jova_adj_reverse_pos", self.n_atoms, P(self.deg_slice), self.adj_ptrs, P(self._rev_pos), stream())
+        return self._rev_pos
 
     @property
     def deg_slice_host(self):
@@ -155,7 +166,8 @@ class GraphConvFunction(torch.autograd.Function):
         out = _empty((n, f_out), xf)
         ws = _empty((int(_lib.lib().jova_graphconv_workspace_floats(f_in, f_out)),), weights[0])
         call("jova_graphconv_fwd", P(xf), 0, ld, n, f_in, f_out, P(topo.deg_slice), topo.adj_ptrs,
-             ptr_array(weights), ptr_array(biases), int(relu), P(out), P(stats), P(ws), stream())
+             ptr_array(weights), ptr_array(biases), int(relu), P(out), P(stats), P(ws),
+             ctypes.c_void_p(topo.deg_slice_host.ctypes.data), stream())
         ctx.topo, ctx.relu, ctx.is_i64, ctx.params, ctx.dims = topo, relu, is_i64, wb, (n, f_in, f_out, ld)
         ctx.save_for_backward(xf, out)
         ctx.weights = weights
@@ -202,7 +214,7 @@ class GraphPoolFunction(torch.autograd.Function):
         n, f = dy.shape
         dx = _empty((n, f), dy)
         call("jova_graphpool_bwd", P(dy), P(arg), n, f, P(topo.deg_slice), topo.adj_ptrs, P(dx), P(topo.sym_flag),
-             int(topo.symmetric), stream())
+             int(topo.symmetric), P(topo.rev_pos), stream())
         return dx, None
 
 

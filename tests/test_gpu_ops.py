@@ -558,12 +558,16 @@ def test_config4_graph_stack_vs_oracle(device):
     tmp = torch.empty_like(o2)
     F_.call("jova_graphpool_fwd", F_.P(o1), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs, F_.P(tmp), F_.P(arg),
             F_.stream())
-    dx_g, dx_s = torch.empty_like(o2), torch.empty_like(o2)
+    dx_g, dx_s, dx_r = torch.empty_like(o2), torch.empty_like(o2), torch.empty_like(o2)
     F_.call("jova_graphpool_bwd", F_.P(dy), F_.P(arg), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs,
-            F_.P(dx_g), F_.P(topo.sym_flag), 1, F_.stream())
+            F_.P(dx_g), F_.P(topo.sym_flag), 1, None, F_.stream())
     F_.call("jova_graphpool_bwd", F_.P(dy), F_.P(arg), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs,
-            F_.P(dx_s), None, 0, F_.stream())
+            F_.P(dx_r), F_.P(topo.sym_flag), 1, F_.P(topo.rev_pos), F_.stream())
+    F_.call("jova_graphpool_bwd", F_.P(dy), F_.P(arg), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs,
+            F_.P(dx_s), None, 0, None, F_.stream())
     H.assert_close(dx_g, dx_s, tol=1e-6, what="pool backward: gather form == atomic scatter form")
+    assert torch.equal(dx_g, dx_r), "pool backward: precomputed reverse positions change the result"
+    assert int((topo.rev_pos == 0xFF).sum()) == 0, "symmetric graph: every edge has its reverse"
     H.assert_close(dx_g.double().sum(0), dy.double().sum(0), tol=1e-6, what="pool backward conserves column sums")
     o3.sum().backward()
     assert torch.isfinite(x3.grad).all()
