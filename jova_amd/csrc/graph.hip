@@ -330,6 +330,34 @@ __device__ __forceinline__ bool locate_tiles_desc(const long long* __restrict__ 
     return false;
 }
 
+// (start, size) of every bucket with ONE batch of scalar loads, then the workgroup's bucket by selects: the dependent
+// load-compare-branch chain of locate_tiles_desc costs a memory round trip per bucket (3 us of a workgroup's life).
+__device__ __forceinline__ bool locate_tiles_batch(const long long* __restrict__ deg_slice, int blk, int group, int& deg,
+                                                   long long& bstart, int& bsize, int& tile0, int& ntile) {
+    long long ds[2 * NB];
+#pragma unroll
+    for (int k = 0; k < 2 * NB; ++k) ds[k] = deg_slice[k];
+    bool found = false;
+    deg = 0; bstart = 0; bsize = 0; tile0 = 0; ntile = 0;
+#pragma unroll
+    for (int d = NB - 1; d >= 0; --d) {
+        const int size = (int)ds[2 * d + 1];
+        const int tiles = (size + GT - 1) / GT;
+        const int groups = (tiles + group - 1) / group;
+        const bool hit = !found && blk < groups;
+        if (hit) {
+            deg = d;
+            bstart = ds[2 * d];
+            bsize = size;
+            tile0 = blk * group;
+            ntile = min(group, tiles - tile0);
+        }
+        found = found || hit;
+        blk -= groups;
+    }
+    return found;
+}
+
 // weights -> B fragments in the permuted k order:
 //   Wq[w][cb][g][lane][s] = W_w[32 cb + (lane & 31)][8 g + 4 (lane >> 5) + s]   (zero padded)
 __global__ void graphconv_pack_dma_kernel(GcParams P, int f_in, int f_out, int kg, int ncb, float* __restrict__ wq) {
@@ -470,7 +498,7 @@ graphconv_fwd_dma_kernel(const float* __restrict__ x, int n_atoms, int ldx, int 
     __shared__ __attribute__((aligned(16))) float lds1[HALF];
     int deg, tile0, ntile, bsize;
     long long bstart;
-    if (!locate_tiles_desc(deg_slice, blockIdx.x, group, deg, bstart, bsize, tile0, ntile)) return;
+    if (!locate_tiles_batch(deg_slice, blockIdx.x, group, deg, bstart, bsize, tile0, ntile)) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int cb = blockIdx.y * 2 + wave;
@@ -794,34 +822,6 @@ extern "C" int jova_debug_bwd_prof(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_prof), sizeof(unsigned long long) * n);
 }
 #endif
-
-// (start, size) of every bucket with ONE batch of scalar loads, then the workgroup's bucket by selects: the dependent
-// load-compare-branch chain of locate_tiles_desc costs a memory round trip per bucket (3 us of a workgroup's life).
-__device__ __forceinline__ bool locate_tiles_batch(const long long* __restrict__ deg_slice, int blk, int group, int& deg,
-                                                   long long& bstart, int& bsize, int& tile0, int& ntile) {
-    long long ds[2 * NB];
-#pragma unroll
-    for (int k = 0; k < 2 * NB; ++k) ds[k] = deg_slice[k];
-    bool found = false;
-    deg = 0; bstart = 0; bsize = 0; tile0 = 0; ntile = 0;
-#pragma unroll
-    for (int d = NB - 1; d >= 0; --d) {
-        const int size = (int)ds[2 * d + 1];
-        const int tiles = (size + GT - 1) / GT;
-        const int groups = (tiles + group - 1) / group;
-        const bool hit = !found && blk < groups;
-        if (hit) {
-            deg = d;
-            bstart = ds[2 * d];
-            bsize = size;
-            tile0 = blk * group;
-            ntile = min(group, tiles - tile0);
-        }
-        found = found || hit;
-        blk -= groups;
-    }
-    return found;
-}
 
 // Work split decided on the host when it knows the bucket sizes (deg_slice_host): workgroups of bucket d are
 // blocks [first[d], first[d] + count), each owns tpw[d] consecutive tiles, sized so that every workgroup has about
@@ -1216,213 +1216,6 @@ graphconv_bwd_dma_kernel(const float* __restrict__ x, int n_atoms, int ldx, int 
                ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
     }
 #endif
-}
-
-// ------------------------------------------------------------------------------------------------ forward, 4-wave form
-// Same skeleton as the backward above (flat steps over (tile, gather round), branch-free index loads and DMA bodies,
-// zero-filled unused planes, host work plan), for the forward product of a 32-atom tile:
-//   out[32][64 cols of this blockIdx.y] = X W_self^T + S W_rel^T        (K = 2 x 8 KG features)
-// Wave w owns output columns 32 (w & 1) .. +31 and HALF of the contraction (feature groups [kh KG/2, (kh+1) KG/2) of
-// both operands, kh = w >> 1), so all four waves have the same MFMA count and LDS traffic; the kh = 1 waves hand
-// their partial tile over through the (otherwise unused) dY plane of the buffer and the kh = 0 waves add it, apply
-// bias / ReLU, store and collect the BatchNorm statistics.  A fragments: one ds_read_b128 per plane per four MFMAs in
-// the permuted k order of graphconv_pack_dma_kernel; operands are summed / prepared one group ahead of their MFMAs.
-template <int KG>
-__global__ void __launch_bounds__(256, (KG > 8 ? 2 : 3))
-graphconv_fwd_dma4_kernel(const float* __restrict__ x, int n_atoms, int ldx, int f_out,
-                          const long long* __restrict__ deg_slice, GcParams P, const float* __restrict__ wq, int ncb,
-                          int relu, float* __restrict__ out, double* __restrict__ stats, int group, BwdPlan plan) {
-    constexpr int NBP = 4;
-    constexpr int HG = KG / 2;                   // feature groups (of 8) per wave
-    constexpr int MAINF = GT * 64, TAILF = GT * 16;
-    constexpr int BUFF = (2 + NBP) * MAINF + (KG > 8 ? (1 + NBP) * TAILF : 0);
-    __shared__ __attribute__((aligned(16))) float lds[BUFF];
-    float* const stage = lds + (1 + NBP) * MAINF;        // [2 column tiles][16 regs][64 lanes]
-    float* const xtail = lds + (2 + NBP) * MAINF;
-    int deg, tile0, ntile, bsize;
-    long long bstart;
-    if (plan.use) {
-        if (!locate_tiles_plan(plan, blockIdx.x, deg, bstart, bsize, tile0, ntile)) return;
-    } else if (!locate_tiles_batch(deg_slice, blockIdx.x, group, deg, bstart, bsize, tile0, ntile)) {
-        return;
-    }
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int i = lane & 31, h = lane >> 5;
-    const int ct = wave & 1, kh = wave >> 1;
-    const int cb = blockIdx.y * 2 + ct;
-    const int col = 32 * cb + i;
-    const bool colok = col < f_out && cb < ncb;
-    const int cbc = cb < ncb ? cb : ncb - 1;
-    const int w_rel = deg > 0 ? 2 * (deg - 1) : 20, w_self = deg == 0 ? 20 : 2 * (deg - 1) + 1;
-    const int sub = tid >> 4;
-    const int* adj_s = deg > 0 ? P.adj[deg - 1] : reinterpret_cast<const int*>(deg_slice);
-    const int degm1 = deg > 0 ? deg - 1 : 0;
-
-    int nidx[2 * NBP];
-    int tidx[KG > 8 ? NBP : 1];
-    auto load_idx = [&](int lrow0, int rows, int nb0) {
-#pragma unroll
-        for (int p = 0; p < NBP; ++p) {
-            const int q = min(nb0 + p, degm1);
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int r = it * 16 + sub;
-                const int rc = r < rows ? r : rows - 1;
-                nidx[2 * p + it] = adj_s[(long long)(lrow0 + rc) * deg + q];
-            }
-            if (KG > 8) {
-                const int r = (tid >> 2) & 31;
-                const int rc = r < rows ? r : rows - 1;
-                tidx[p] = adj_s[(long long)(lrow0 + rc) * deg + q];
-            }
-        }
-    };
-    auto issue = [&](int t, int rd) {
-        const int lrow0 = (tile0 + t) * GT;
-        const int rows = min(GT, bsize - lrow0);
-        const long long row0 = bstart + lrow0;
-        const int cnt = min(NBP, deg - rd * NBP);
-#define JOVA_IS(X_, C_) bwd_issue<KG, false, NBP, X_, false, C_>(x, nullptr, nullptr, n_atoms, ldx, row0, rows, nidx, tidx, lds, tid)
-#define JOVA_IS_SW(X_)                                                                                                 \
-    switch (cnt) {                                                                                                     \
-        case 1: JOVA_IS(X_, 1); break;                                                                                 \
-        case 2: JOVA_IS(X_, 2); break;                                                                                 \
-        case 3: JOVA_IS(X_, 3); break;                                                                                 \
-        case 4: JOVA_IS(X_, 4); break;                                                                                 \
-        default: JOVA_IS(X_, 0); break;                                                                                \
-    }
-        if (rd == 0) { JOVA_IS_SW(true) } else { JOVA_IS_SW(false) }
-#undef JOVA_IS_SW
-#undef JOVA_IS
-    };
-    auto zero_planes = [&](int from) {
-        for (int e = tid; e < (NBP - from) * MAINF; e += 256) lds[(1 + from) * MAINF + e] = 0.f;
-        if (KG > 8)
-            for (int e = tid; e < (NBP - from) * TAILF; e += 256) xtail[(1 + from) * TAILF + e] = 0.f;
-    };
-
-    const int nrounds = deg > NBP ? (deg + NBP - 1) / NBP : 1;
-    const int nsteps = ntile * nrounds;
-    const int cnt_last = min(NBP, deg - (nrounds - 1) * NBP);
-    if (deg < NBP) zero_planes(max(deg, 0));
-    load_idx(tile0 * GT, min(GT, bsize - tile0 * GT), 0);
-    issue(0, 0);
-    int t1 = nrounds > 1 ? 0 : 1, rd1 = nrounds > 1 ? 1 : 0;     // step s + 1
-    if (nsteps > 1) load_idx((tile0 + t1) * GT, min(GT, bsize - (tile0 + t1) * GT), rd1 * NBP);
-
-    // B fragments of this wave's half of the contraction
-    float4 bself[HG], brel[HG];
-    {
-        const float4* ws = reinterpret_cast<const float4*>(wq) + (((long long)w_self * ncb + cbc) * KG + kh * HG) * 64 + lane;
-        const float4* wr = reinterpret_cast<const float4*>(wq) + (((long long)w_rel * ncb + cbc) * KG + kh * HG) * 64 + lane;
-#pragma unroll
-        for (int g = 0; g < HG; ++g) {
-            bself[g] = ws[g * 64];
-            brel[g] = wr[g * 64];
-        }
-    }
-    float bias = 0.f;
-    if (colok) {
-        bias = P.b[w_self][col];
-        if (deg > 0) bias += P.b[w_rel][col];
-    }
-    double s = 0.0, q = 0.0;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-    // fragment of feature group G (absolute) of plane p for atom i: main image G < 8, tail image G = 8, 9
-    // (an address select, not a branch: G is wave-uniform but only known at run time)
-    auto frag = [&](int p, int G) -> float4 {
-        const int om = p * MAINF + i * 64 + (((2 * G + h) ^ (i & 15)) << 2);
-        const int ot = (2 + NBP) * MAINF + p * TAILF + i * 16 + (((2 * (G - 8) + h) ^ ((i >> 2) & 3)) << 2);
-        return *reinterpret_cast<const float4*>(lds + ((KG == 8 || G < 8) ? om : ot));
-    };
-
-    int t = 0, rd = 0;
-    for (int st = 0; st < nsteps; ++st) {
-        const int lrow0 = (tile0 + t) * GT;
-        const int rows = min(GT, bsize - lrow0);
-        const long long row0 = bstart + lrow0;
-        const bool first = rd == 0, last = rd == nrounds - 1;
-        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this step's rows landed
-        __syncthreads();                         // ... for every wave; the hand-over area of the last tile is free
-        // operands one group ahead of their MFMAs (see the backward): raw fragments two ahead
-        float4 rx[2], rn[2][NBP], ox[2], os[2];
-        auto load = [&](int b, int g) {
-            const int G = kh * HG + g;
-            rx[b] = frag(0, G);
-#pragma unroll
-            for (int p = 0; p < NBP; ++p) rn[b][p] = frag(1 + p, G);
-        };
-        auto prep = [&](int b) {
-            float4 v = rx[b];
-            if (!first) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            ox[b] = v;
-            float4 a = rn[b][0];
-#pragma unroll
-            for (int p = 1; p < NBP; ++p) { a.x += rn[b][p].x; a.y += rn[b][p].y; a.z += rn[b][p].z; a.w += rn[b][p].w; }
-            os[b] = a;
-        };
-        load(0, 0);
-        if (HG > 1) load(1, 1);
-        prep(0);
-#pragma unroll
-        for (int g = 0; g < HG; ++g) {
-            const int b = g & 1;
-            const float4 cx = ox[b], cs = os[b];
-            if (g + 1 < HG) prep(b ^ 1);
-            if (g + 2 < HG) load(b, g + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cx.x, bself[g].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cs.x, brel[g].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cx.y, bself[g].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cs.y, brel[g].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cx.z, bself[g].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cs.z, brel[g].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cx.w, bself[g].w, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cs.w, brel[g].w, acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (last && kh == 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) stage[(ct * 16 + r) * 64 + lane] = acc[r];
-        }
-        __syncthreads();                         // this step's plane reads are done; the partial tiles are handed over
-        if (st + 1 < nsteps) {
-            if (nrounds > 1 && cnt_last < NBP && rd1 == nrounds - 1) zero_planes(cnt_last);
-            issue(t1, rd1);
-            int t2 = t1, rd2 = rd1 + 1;
-            if (rd2 == nrounds) { rd2 = 0; ++t2; }
-            if (st + 2 < nsteps) load_idx((tile0 + t2) * GT, min(GT, bsize - (tile0 + t2) * GT), rd2 * NBP);
-            t = t1; rd = rd1; t1 = t2; rd1 = rd2;
-        }
-        if (last) {
-            if (kh == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mfma32_row(r, lane);
-                    float v = acc[r] + stage[(ct * 16 + r) * 64 + lane] + bias;
-                    if (relu) v = fmaxf(v, 0.f);
-                    if (row < rows && colok) {
-                        out[(row0 + row) * f_out + col] = v;
-                        s += (double)v;
-                        q += (double)v * (double)v;
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        }
-    }
-    if (stats && kh == 0) {
-        s += __shfl_xor(s, 32, 64);
-        q += __shfl_xor(q, 32, 64);
-        if (lane < 32 && colok) {
-            atomicAdd(&stats[col], s);
-            atomicAdd(&stats[f_out + col], q);
-        }
-    }
 }
 
 // dx[i] (holds T_i) += sum of the neighbours' G rows; 16 lanes per atom, float4, four neighbour rows in flight.
@@ -1991,7 +1784,7 @@ extern "C" int jova_atoms_to_f32(const int64_t* atoms, int64_t n_atoms, int f, i
 extern "C" int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t ld_atoms, int64_t n_atoms, int f_in, int f_out,
                                   const int64_t* deg_slice, const int32_t* const* adj, const float* const* weight,
                                   const float* const* bias, int relu, float* out, double* bn_stats,
-                                  float* packed_ws, const int64_t* deg_slice_host, void* stream) {
+                                  float* packed_ws, void* stream) {
     JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 31), "graphconv_fwd: n_atoms %lld out of range", (long long)n_atoms);
     JOVA_CHECK_ARG(f_in >= 1 && f_in <= 128, "graphconv_fwd: f_in %d not in [1,128]", f_in);
     JOVA_CHECK_ARG(f_out >= 1, "graphconv_fwd: f_out %d", f_out);
@@ -2014,28 +1807,6 @@ extern "C" int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t l
                            packed_ws);
         JOVA_CHECK_LAUNCH("graphconv_pack_dma");
         const int tiles = cdiv(n_atoms, GT);
-        if (!getenv("JOVA_GRAPHCONV_OLD_FWD")) {
-            // 4-wave form; work split on the host when it knows the bucket sizes
-            BwdPlan plan;
-            memset(&plan, 0, sizeof(plan));
-            int group4 = tiles > 2048 ? cdiv(tiles, 2000) : 1;
-            dim3 grid4(cdiv(tiles, group4) + NB, cdiv(f_out, 64));
-            if (deg_slice_host) {
-                const int nblk = make_plan(deg_slice_host, n_atoms, 4, kg == 8 ? 3 : 2, plan);
-                if (nblk < 0) return JOVA_ERR_ARG;
-                grid4.x = nblk;
-            }
-            if (kg == 8)
-                hipLaunchKernelGGL((graphconv_fwd_dma4_kernel<8>), grid4, dim3(256), 0, s, (const float*)atoms,
-                                   (int)n_atoms, (int)ld_atoms, f_out, (const long long*)deg_slice, P, packed_ws, ncb,
-                                   relu, out, bn_stats, group4, plan);
-            else
-                hipLaunchKernelGGL((graphconv_fwd_dma4_kernel<10>), grid4, dim3(256), 0, s, (const float*)atoms,
-                                   (int)n_atoms, (int)ld_atoms, f_out, (const long long*)deg_slice, P, packed_ws, ncb,
-                                   relu, out, bn_stats, group4, plan);
-            JOVA_CHECK_LAUNCH("graphconv_fwd_dma4");
-            return JOVA_OK;
-        }
         const int group = tiles > 2048 ? 4 : (tiles > 512 ? 2 : 1);
         dim3 grid(cdiv(tiles, group) + NB, cdiv(f_out, 64));
         static int npl_env = -1;

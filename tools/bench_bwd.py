@@ -28,6 +28,11 @@ for name, y in which:
         x2.grad = None
         y.backward(g64, retain_graph=True)
     torch.cuda.synchronize()
+if "fwd" in sys.argv:
+    with torch.no_grad():
+        for r in range(4):
+            (conv1(glist) if "l1last" in sys.argv else conv2([x2] + glist[1:]))
+    torch.cuda.synchronize()
 if os.environ.get("JOVA_LIB"):
     import ctypes
     from jova_amd import _lib
@@ -35,6 +40,8 @@ if os.environ.get("JOVA_LIB"):
     buf = (ctypes.c_ulonglong * (4096 * 8))()
     L.jova_debug_bwd_prof(buf, 4096 * 8)
     a = np.array(buf[:], dtype=np.uint64).reshape(4096, 8)
+    print("one WG (last writer): issue cycles %d, epilogue cycles %d (whole loop)" % (a[4095, 6], a[4095, 7]))
+    a = a[:4095]
     a = a[a[:, 6] > 0]
     t0 = a[:, 0].min()
     ent, ls, le, fl = [(a[:, k] - t0).astype(np.float64) / 100.0 for k in range(4)]
