@@ -108,59 +108,90 @@ def cpu_baseline(pool, hp, batch_ids, state_dict, n_steps, threads):
 
 
 def graph_stress(device, reps=20, full=True):
-    """Config 4: 4096 molecules (~246 k atoms, degree <= 10): graph kernels against the HBM roofline."""
+    """Config 4: 4096 molecules (~246 k atoms, degree <= 10): graph kernels against the HBM roofline.
+
+    Every kernel is launched through the C ABI (jova_amd._lib.call) on pre-allocated buffers, `reps` launches back to
+    back between two HIP events on torch's current stream (the stream the library launches on), so the figure is the
+    kernel's own duration, not the Python / autograd dispatch around it (which is longer than these kernels)."""
     from jova_amd.data.collate import process_gconv_view_data
-    from jova_amd.nn.layers import GraphConvLayer, GraphPool
+    from jova_amd.nn.layers import GraphConvLayer
+    from jova_amd._lib import P, call, lib, ptr_array, stream
+    import ctypes
     pool = synth.SyntheticPool("graph4k", seed=1)
     mols = [ConvMol(f, a, smiles=str(i)) for i, (f, a) in enumerate(pool.mols)]
     glist = process_gconv_view_data(mols, device)
+    topo = F_.topology_of(glist)
     n = glist[0].shape[0]
     e = sum(int(a.numel()) for a in glist[4:])
-    conv1, conv2, gp = GraphConvLayer(75, 64).to(device), GraphConvLayer(64, 64).to(device), GraphPool()
+    conv1, conv2 = GraphConvLayer(75, 64).to(device), GraphConvLayer(64, 64).to(device)
+    x1 = topo.atoms_f32(glist[0])                       # fp32 copy of the int64 features, once per batch
     x2 = torch.randn(n, 64, device=device).relu_()
     res = []
 
-    def timed(name, fn, nbytes):
+    def timed(name, fn, nbytes, launches=1):
         fn()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for a, b in ev:
-            a.record()
-            fn()
-            b.record()
         torch.cuda.synchronize()
-        ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
         gbs = nbytes / (ms * 1e-3) / 1e9
         res.append(dict(kernel=name, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(gbs / HBM_PEAK_GBS, 4), us=round(ms * 1e3, 1), algorithmic_bytes=int(nbytes)))
+                        frac=round(gbs / HBM_PEAK_GBS, 4), us=round(ms * 1e3, 1), algorithmic_bytes=int(nbytes),
+                        launches=launches))
 
+    def wb(layer):
+        w = [l.weight for l in layer.linear_layers]
+        bias = [l.bias for l in layer.linear_layers]
+        return w, bias, ptr_array(w), ptr_array(bias)
+
+    st = stream()
+    ds, adj = P(topo.deg_slice), topo.adj_ptrs
+    dsh = ctypes.c_void_p(topo.deg_slice_host.ctypes.data)
+    w1, b1, pw1, pb1 = wb(conv1)
+    w2, b2, pw2, pb2 = wb(conv2)
+    out = torch.empty(n, 64, device=device)
+    arg = torch.empty(n, 64, dtype=torch.uint8, device=device)
+    ws1 = torch.empty(int(lib().jova_graphconv_workspace_floats(75, 64)), device=device)
+    ws2 = torch.empty(int(lib().jova_graphconv_workspace_floats(64, 64)), device=device)
     wbytes = 4 * 21 * 65 * 64
-    gl2 = [x2] + glist[1:]
-    with torch.no_grad():
-        # layer 1: the batch's int64 atom features are converted to fp32 once per batch (cached on the topology),
-        # so the per-step kernel reads 4-byte features: algorithmic bytes as SURVEY.md section 8d
-        timed("graphconv_fwd_l1(75->64)", lambda: conv1(glist), 4 * (n * 75 + n * 64 + e) + 4 * 21 * 76 * 64)
-        timed("graphconv_fwd_l2(64->64)", lambda: conv2(gl2), 4 * (n * 64 + n * 64 + e) + wbytes)
-        timed("graphpool_fwd(64)", lambda: gp(gl2), 4 * (2 * n * 64 + e) + n * 64)
+    # layer 1: the batch's int64 atom features are converted to fp32 once per batch (cached on the topology), so the
+    # per-step kernel reads 4-byte features: algorithmic bytes as SURVEY.md section 8d
+    timed("graphconv_fwd_l1(75->64)", lambda: call("jova_graphconv_fwd", P(x1), 0, x1.shape[1], n, 75, 64, ds, adj, pw1,
+                                                   pb1, 1, P(out), None, P(ws1), st),
+          4 * (n * 75 + n * 64 + e) + 4 * 21 * 76 * 64, launches=2)
+    timed("graphconv_fwd_l2(64->64)", lambda: call("jova_graphconv_fwd", P(x2), 0, 64, n, 64, 64, ds, adj, pw2, pb2, 1,
+                                                   P(out), None, P(ws2), st),
+          4 * (n * 64 + n * 64 + e) + wbytes, launches=2)
+    timed("graphpool_fwd(64)", lambda: call("jova_graphpool_fwd", P(x2), n, 64, ds, adj, P(out), P(arg), st),
+          4 * (2 * n * 64 + e) + n * 64)
     if full:
-        # backward kernels: parameters get .grad buffers first so the kernels accumulate in place (as in the trainer).
-        # In the model the BatchNorm behind each convolution applies the backward of the convolution's ReLU (it reads
-        # that output anyway), so the convolution's backward receives dZ: timed here with activation=None layers.
-        conv1b, conv2b = GraphConvLayer(75, 64, activation=None).to(device), GraphConvLayer(64, 64, activation=None).to(device)
-        for m in (conv1b, conv2b):
-            for prm in m.parameters():
-                prm.grad = torch.zeros_like(prm)
-        x2g = x2.clone().requires_grad_(True)
-        gl2g = [x2g] + glist[1:]
-        g64 = torch.randn(n, 64, device=device)
-        y1, y2, yp = conv1b(glist), conv2b(gl2g), gp(gl2g)
-
-        def bwd(y):
-            x2g.grad = None
-            y.backward(g64, retain_graph=True)
-        timed("graphconv_bwd_l1(dW only)", lambda: bwd(y1), 4 * (n * 64 + n * 75 + e) + 2 * 4 * 21 * 76 * 64)
-        timed("graphconv_bwd_l2(dW + dX, 2 launches)", lambda: bwd(y2), 4 * (n * 64 + 3 * n * 64 + e) + 2 * wbytes)
-        timed("graphpool_bwd(64)", lambda: bwd(yp), 4 * (2 * n * 64 + e) + n * 64)
-    return dict(workload="graph4k: 4096 molecules, %d atoms, %d directed edges" % (n, e), kernels=res)
+        # backward kernels accumulate into gradient buffers (as in the trainer).  In the model the BatchNorm behind
+        # each convolution applies the backward of the convolution's ReLU (it reads that output anyway), so the
+        # convolution's backward receives dZ: y_or_null = NULL here.
+        dw1 = [torch.zeros_like(t) for t in w1]; db1 = [torch.zeros_like(t) for t in b1]
+        dw2 = [torch.zeros_like(t) for t in w2]; db2 = [torch.zeros_like(t) for t in b2]
+        pdw1, pdb1, pdw2, pdb2 = ptr_array(dw1), ptr_array(db1), ptr_array(dw2), ptr_array(db2)
+        dz = torch.randn(n, 64, device=device)
+        dx, gbuf = torch.empty(n, 64, device=device), torch.empty(n, 64, device=device)
+        sym = int(topo.symmetric)
+        timed("graphconv_bwd_l1(dW only)",
+              lambda: call("jova_graphconv_bwd", P(x1), 0, x1.shape[1], n, 75, 64, ds, adj, pw1, P(dz), None, pdw1, pdb1,
+                           None, None, P(topo.sym_flag), dsh, st),
+              4 * (n * 64 + n * 75 + e) + 2 * 4 * 21 * 76 * 64)
+        timed("graphconv_bwd_l2(dW + dX, 2 launches)",
+              lambda: call("jova_graphconv_bwd", P(x2), 0, 64, n, 64, 64, ds, adj, pw2, P(dz), None, pdw2, pdb2, P(dx),
+                           P(gbuf), P(topo.sym_flag), dsh, st),
+              4 * (n * 64 + 3 * n * 64 + e) + 2 * wbytes, launches=2)
+        timed("graphpool_bwd(64)", lambda: call("jova_graphpool_bwd", P(dz), P(arg), n, 64, ds, adj, P(dx),
+                                                P(topo.sym_flag), sym, P(topo.rev_pos), st),
+              4 * (2 * n * 64 + e) + n * 64)
+    return dict(workload="graph4k: 4096 molecules, %d atoms, %d directed edges" % (n, e), kernels=res,
+                note="kernel durations: reps launches through the C ABI between two HIP events; fwd = weight re-pack + "
+                     "kernel; conv backward takes dZ (ReLU mask applied by the BatchNorm backward, as in the model)")
 
 
 def main():
