@@ -128,7 +128,21 @@ def graph_stress(device, reps=20, full=True):
     x2 = torch.randn(n, 64, device=device).relu_()
     res = []
 
-    def timed(name, fn, nbytes, launches=1):
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_graph.json")) as f:
+            pmc = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        pmc = {}
+
+    def traffic_of(*kernels):
+        """L2-fabric bytes per launch from the committed PMC passes (profiles/r01_pmc_graph.json), summed over the
+        kernels of one entry; None when a kernel is missing there."""
+        try:
+            return int(sum(pmc[k]["traffic_bytes_per_launch"] for k in kernels))
+        except KeyError:
+            return None
+
+    def timed(name, fn, nbytes, launches=1, kernels=()):
         fn()
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -141,7 +155,7 @@ def graph_stress(device, reps=20, full=True):
         gbs = nbytes / (ms * 1e-3) / 1e9
         res.append(dict(kernel=name, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(gbs / HBM_PEAK_GBS, 4), us=round(ms * 1e3, 1), algorithmic_bytes=int(nbytes),
-                        launches=launches))
+                        launches=launches, traffic=traffic_of(*kernels) if kernels else None))
 
     def wb(layer):
         w = [l.weight for l in layer.linear_layers]
@@ -162,12 +176,12 @@ def graph_stress(device, reps=20, full=True):
     # per-step kernel reads 4-byte features: algorithmic bytes as SURVEY.md section 8d
     timed("graphconv_fwd_l1(75->64)", lambda: call("jova_graphconv_fwd", P(x1), 0, x1.shape[1], n, 75, 64, ds, adj, pw1,
                                                    pb1, 1, P(out), None, P(ws1), st),
-          4 * (n * 75 + n * 64 + e) + 4 * 21 * 76 * 64, launches=2)
+          4 * (n * 75 + n * 64 + e) + 4 * 21 * 76 * 64, launches=2, kernels=("graphconv_fwd_dma_kernel<10, 4>",))
     timed("graphconv_fwd_l2(64->64)", lambda: call("jova_graphconv_fwd", P(x2), 0, 64, n, 64, 64, ds, adj, pw2, pb2, 1,
                                                    P(out), None, P(ws2), st),
-          4 * (n * 64 + n * 64 + e) + wbytes, launches=2)
+          4 * (n * 64 + n * 64 + e) + wbytes, launches=2, kernels=("graphconv_fwd_dma_kernel<8, 4>",))
     timed("graphpool_fwd(64)", lambda: call("jova_graphpool_fwd", P(x2), n, 64, ds, adj, P(out), P(arg), st),
-          4 * (2 * n * 64 + e) + n * 64)
+          4 * (2 * n * 64 + e) + n * 64, kernels=("graphpool_fwd_v4_kernel",))
     if full:
         # backward kernels accumulate into gradient buffers (as in the trainer).  In the model the BatchNorm behind
         # each convolution applies the backward of the convolution's ReLU (it reads that output anyway), so the
@@ -181,14 +195,16 @@ def graph_stress(device, reps=20, full=True):
         timed("graphconv_bwd_l1(dW only)",
               lambda: call("jova_graphconv_bwd", P(x1), 0, x1.shape[1], n, 75, 64, ds, adj, pw1, P(dz), None, pdw1, pdb1,
                            None, None, P(topo.sym_flag), dsh, st),
-              4 * (n * 64 + n * 75 + e) + 2 * 4 * 21 * 76 * 64)
+              4 * (n * 64 + n * 75 + e) + 2 * 4 * 21 * 76 * 64,
+              kernels=("graphconv_bwd_dma_kernel<10, false, false, 4, false>",))
         timed("graphconv_bwd_l2(dW + dX, 2 launches)",
               lambda: call("jova_graphconv_bwd", P(x2), 0, 64, n, 64, 64, ds, adj, pw2, P(dz), None, pdw2, pdb2, P(dx),
                            P(gbuf), P(topo.sym_flag), dsh, st),
-              4 * (n * 64 + 3 * n * 64 + e) + 2 * wbytes, launches=2)
+              4 * (n * 64 + 3 * n * 64 + e) + 2 * wbytes, launches=2,
+              kernels=("graphconv_bwd_dma_kernel<8, true, false, 4, false>", "graphconv_bwd_dx_v4_kernel"))
         timed("graphpool_bwd(64)", lambda: call("jova_graphpool_bwd", P(dz), P(arg), n, 64, ds, adj, P(dx),
                                                 P(topo.sym_flag), sym, P(topo.rev_pos), st),
-              4 * (2 * n * 64 + e) + n * 64)
+              4 * (2 * n * 64 + e) + n * 64, kernels=("graphpool_bwd_v5_kernel",))
     return dict(workload="graph4k: 4096 molecules, %d atoms, %d directed edges" % (n, e), kernels=res,
                 note="kernel durations: reps launches through the C ABI between two HIP events; fwd = weight re-pack + "
                      "kernel; conv backward takes dZ (ReLU mask applied by the BatchNorm backward, as in the model)")
