@@ -175,10 +175,10 @@ def graph_stress(device, reps=20, full=True):
     # layer 1: the batch's int64 atom features are converted to fp32 once per batch (cached on the topology), so the
     # per-step kernel reads 4-byte features: algorithmic bytes as SURVEY.md section 8d
     timed("graphconv_fwd_l1(75->64)", lambda: call("jova_graphconv_fwd", P(x1), 0, x1.shape[1], n, 75, 64, ds, adj, pw1,
-                                                   pb1, 1, P(out), None, P(ws1), st),
+                                                   pb1, 1, P(out), None, P(ws1), dsh, st),
           4 * (n * 75 + n * 64 + e) + 4 * 21 * 76 * 64, launches=2, kernels=("graphconv_fwd_dma_kernel<10, 4>",))
     timed("graphconv_fwd_l2(64->64)", lambda: call("jova_graphconv_fwd", P(x2), 0, 64, n, 64, 64, ds, adj, pw2, pb2, 1,
-                                                   P(out), None, P(ws2), st),
+                                                   P(out), None, P(ws2), dsh, st),
           4 * (n * 64 + n * 64 + e) + wbytes, launches=2, kernels=("graphconv_fwd_dma_kernel<8, 4>",))
     timed("graphpool_fwd(64)", lambda: call("jova_graphpool_fwd", P(x2), n, 64, ds, adj, P(out), P(arg), st),
           4 * (2 * n * 64 + e) + n * 64, kernels=("graphpool_fwd_v4_kernel",))

@@ -33,11 +33,12 @@ int jova_abi_version(void);
  * in linear_layers order (rel_1, self_1, ..., rel_10, self_10, self_0), weight[k] = [f_out, f_in].
  * out [N, f_out] = act( W_rel[d] . sum_nbr x + b_rel[d] + W_self[d] . x + b_self[d] ).
  * bn_stats (optional, fp64 [2, f_out]): column sum / sum of squares of `out` for the BatchNorm1d that follows.
- * packed_ws: scratch of jova_graphconv_workspace_floats(f_in, f_out) floats. */
+ * packed_ws: scratch of jova_graphconv_workspace_floats(f_in, f_out) floats.
+ * deg_slice_host: optional HOST copy of deg_slice (see jova_graphconv_bwd). */
 int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t ld_atoms, int64_t n_atoms, int f_in, int f_out,
                        const int64_t* deg_slice, const int32_t* const* adj, const float* const* weight,
                        const float* const* bias, int relu, float* out, double* bn_stats, float* packed_ws,
-                       void* stream);
+                       const int64_t* deg_slice_host, void* stream);
 /* int64 atom features [n, f] -> fp32 rows padded with zeros to ld floats (ld % 4 == 0 enables 16-byte row loads in
  * jova_graphconv_fwd / _bwd; done once per batch: the features of a batch never change) */
 int jova_atoms_to_f32(const int64_t* atoms, int64_t n_atoms, int f, int ld, float* out, void* stream);

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("JOVA_LIB") or os.path.join(_HERE, "libjova_hip.so")  
 
 # signature codes: p = pointer, i = int, q = int64, f = float, Q = uint64
 _SIGS = {
-    "jova_graphconv_fwd": "piqqiipppp" + "ipppp",
+    "jova_graphconv_fwd": "piqqiipppp" + "ippppp",
     "jova_atoms_to_f32": "pqiipp",
     "jova_graphconv_bwd": "piqqiippp" + "pppp" + "ppppp",
     "jova_adj_symmetry": "qpppp",

@@ -358,6 +358,36 @@ __device__ __forceinline__ bool locate_tiles_batch(const long long* __restrict__
     return found;
 }
 
+// Work split decided on the host when it knows the bucket sizes (deg_slice_host): workgroups of bucket d are
+// blocks [first[d], first[d] + count), each owns tpw[d] consecutive tiles, sized so that every workgroup has about
+// the same number of steps and all of them are resident at once (one prologue / flush per workgroup slot).
+struct BwdPlan {
+    int use;
+    int first[NB + 1];       // first[d] .. first[d - 1] - 1 are the blocks of bucket d (buckets in descending order)
+    int tpw[NB];
+    int start[NB];
+    int size[NB];
+};
+
+__device__ __forceinline__ bool locate_tiles_plan(const BwdPlan& pl, int blk, int& deg, long long& bstart, int& bsize,
+                                                  int& tile0, int& ntile) {
+    bool found = false;
+    deg = 0; bstart = 0; bsize = 0; tile0 = 0; ntile = 0;
+#pragma unroll
+    for (int d = NB - 1; d >= 0; --d) {
+        const int b0 = pl.first[d + 1], b1 = pl.first[d];          // first[NB] = 0
+        if (blk >= b0 && blk < b1) {
+            found = true;
+            deg = d;
+            bstart = pl.start[d];
+            bsize = pl.size[d];
+            tile0 = (blk - b0) * pl.tpw[d];
+            ntile = min(pl.tpw[d], (bsize + GT - 1) / GT - tile0);
+        }
+    }
+    return found && ntile > 0;
+}
+
 // weights -> B fragments in the permuted k order:
 //   Wq[w][cb][g][lane][s] = W_w[32 cb + (lane & 31)][8 g + 4 (lane >> 5) + s]   (zero padded)
 __global__ void graphconv_pack_dma_kernel(GcParams P, int f_in, int f_out, int kg, int ncb, float* __restrict__ wq) {
@@ -492,13 +522,17 @@ template <int KG, int NPL>
 __global__ void __launch_bounds__(128, (NPL <= 4 ? 2 : 1))
 graphconv_fwd_dma_kernel(const float* __restrict__ x, int n_atoms, int ldx, int f_out,
                          const long long* __restrict__ deg_slice, GcParams P, const float* __restrict__ wq, int ncb,
-                         int relu, float* __restrict__ out, double* __restrict__ stats, int group) {
+                         int relu, float* __restrict__ out, double* __restrict__ stats, int group, BwdPlan plan) {
     constexpr int HALF = (NPL / 2) * GT * (KG > 8 ? 80 : 64);
     __shared__ __attribute__((aligned(16))) float lds0[HALF];
     __shared__ __attribute__((aligned(16))) float lds1[HALF];
     int deg, tile0, ntile, bsize;
     long long bstart;
-    if (!locate_tiles_batch(deg_slice, blockIdx.x, group, deg, bstart, bsize, tile0, ntile)) return;
+    if (plan.use) {
+        if (!locate_tiles_plan(plan, blockIdx.x, deg, bstart, bsize, tile0, ntile)) return;
+    } else if (!locate_tiles_batch(deg_slice, blockIdx.x, group, deg, bstart, bsize, tile0, ntile)) {
+        return;
+    }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int cb = blockIdx.y * 2 + wave;
@@ -822,36 +856,6 @@ extern "C" int jova_debug_bwd_prof(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_prof), sizeof(unsigned long long) * n);
 }
 #endif
-
-// Work split decided on the host when it knows the bucket sizes (deg_slice_host): workgroups of bucket d are
-// blocks [first[d], first[d] + count), each owns tpw[d] consecutive tiles, sized so that every workgroup has about
-// the same number of steps and all of them are resident at once (one prologue / flush per workgroup slot).
-struct BwdPlan {
-    int use;
-    int first[NB + 1];       // first[d] .. first[d - 1] - 1 are the blocks of bucket d (buckets in descending order)
-    int tpw[NB];
-    int start[NB];
-    int size[NB];
-};
-
-__device__ __forceinline__ bool locate_tiles_plan(const BwdPlan& pl, int blk, int& deg, long long& bstart, int& bsize,
-                                                  int& tile0, int& ntile) {
-    bool found = false;
-    deg = 0; bstart = 0; bsize = 0; tile0 = 0; ntile = 0;
-#pragma unroll
-    for (int d = NB - 1; d >= 0; --d) {
-        const int b0 = pl.first[d + 1], b1 = pl.first[d];          // first[NB] = 0
-        if (blk >= b0 && blk < b1) {
-            found = true;
-            deg = d;
-            bstart = pl.start[d];
-            bsize = pl.size[d];
-            tile0 = (blk - b0) * pl.tpw[d];
-            ntile = min(pl.tpw[d], (bsize + GT - 1) / GT - tile0);
-        }
-    }
-    return found && ntile > 0;
-}
 
 // DMA requests of one step, straight-line: own rows (XOWN), dY / Y rows (ZLOAD) and CNT neighbour planes.
 // Buffer layout (floats): [own | N_0 .. N_{NBP-1} | dY | Y (MASK)] main planes of GT x 64, then (KG > 8) the
@@ -1784,7 +1788,7 @@ extern "C" int jova_atoms_to_f32(const int64_t* atoms, int64_t n_atoms, int f, i
 extern "C" int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t ld_atoms, int64_t n_atoms, int f_in, int f_out,
                                   const int64_t* deg_slice, const int32_t* const* adj, const float* const* weight,
                                   const float* const* bias, int relu, float* out, double* bn_stats,
-                                  float* packed_ws, void* stream) {
+                                  float* packed_ws, const int64_t* deg_slice_host, void* stream) {
     JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 31), "graphconv_fwd: n_atoms %lld out of range", (long long)n_atoms);
     JOVA_CHECK_ARG(f_in >= 1 && f_in <= 128, "graphconv_fwd: f_in %d not in [1,128]", f_in);
     JOVA_CHECK_ARG(f_out >= 1, "graphconv_fwd: f_out %d", f_out);
@@ -1807,7 +1811,8 @@ extern "C" int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t l
                            packed_ws);
         JOVA_CHECK_LAUNCH("graphconv_pack_dma");
         const int tiles = cdiv(n_atoms, GT);
-        const int group = tiles > 2048 ? 4 : (tiles > 512 ? 2 : 1);
+        int group = tiles > 2048 ? 4 : (tiles > 512 ? 2 : 1);
+        if (getenv("JOVA_FWD_GROUP")) group = atoi(getenv("JOVA_FWD_GROUP"));
         dim3 grid(cdiv(tiles, group) + NB, cdiv(f_out, 64));
         static int npl_env = -1;
         if (npl_env < 0) {
@@ -1815,10 +1820,19 @@ extern "C" int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t l
             npl_env = e ? atoi(e) : 0;
         }
         const int npl = npl_env == 8 ? 8 : 4;
+        // bucket sizes known on the host: workgroups of about equal length (a tile of degree d takes ceil(d / (npl - 1))
+        // gather rounds), four per CU
+        BwdPlan plan;
+        memset(&plan, 0, sizeof(plan));
+        if (deg_slice_host && !getenv("JOVA_FWD_NOPLAN")) {
+            const int nblk = make_plan(deg_slice_host, n_atoms, npl - 1, getenv("JOVA_FWD_SLOTS") ? atoi(getenv("JOVA_FWD_SLOTS")) : (npl == 4 ? 4 : 2), plan);
+            if (nblk < 0) return JOVA_ERR_ARG;
+            grid.x = nblk;
+        }
 #define GC_DMA(KG_, NPL_)                                                                                              \
     hipLaunchKernelGGL((graphconv_fwd_dma_kernel<KG_, NPL_>), grid, dim3(128), 0, s, (const float*)atoms,              \
                        (int)n_atoms, (int)ld_atoms, f_out, (const long long*)deg_slice, P, packed_ws, ncb, relu, out,  \
-                       bn_stats, group)
+                       bn_stats, group, plan)
         if (kg == 8 && npl == 4) GC_DMA(8, 4);
         else if (kg == 8) GC_DMA(8, 8);
         else if (npl == 4) GC_DMA(10, 4);

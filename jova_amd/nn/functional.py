@@ -166,7 +166,8 @@ class GraphConvFunction(torch.autograd.Function):
         out = _empty((n, f_out), xf)
         ws = _empty((int(_lib.lib().jova_graphconv_workspace_floats(f_in, f_out)),), weights[0])
         call("jova_graphconv_fwd", P(xf), 0, ld, n, f_in, f_out, P(topo.deg_slice), topo.adj_ptrs,
-             ptr_array(weights), ptr_array(biases), int(relu), P(out), P(stats), P(ws), stream())
+             ptr_array(weights), ptr_array(biases), int(relu), P(out), P(stats), P(ws),
+             ctypes.c_void_p(topo.deg_slice_host.ctypes.data), stream())
         ctx.topo, ctx.relu, ctx.is_i64, ctx.params, ctx.dims = topo, relu, is_i64, wb, (n, f_in, f_out, ld)
         ctx.save_for_backward(xf, out)
         ctx.weights = weights

@@ -92,7 +92,7 @@ def test_abi_library_exports_every_declared_symbol():
 def test_abi_argument_errors_are_reported_without_a_gpu():
     from jova_amd import _lib
     with pytest.raises(RuntimeError, match="f_in"):
-        _lib.call("jova_graphconv_fwd", None, 0, 500, 10, 500, 64, None, None, None, None, 1, None, None, None, None)
+        _lib.call("jova_graphconv_fwd", None, 0, 500, 10, 500, 64, None, None, None, None, 1, None, None, None, None, None)
     with pytest.raises(RuntimeError, match="unit stride"):
         _lib.call("jova_gemm_f32", ctypes.c_void_p(16), 3, 3, ctypes.c_void_p(16), 1, 4, ctypes.c_void_p(16), 4, 4, 4,
                   4, 1.0, None, None, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, None)
