@@ -117,7 +117,7 @@ class OverlappedGradSync(object):
     """Gradient all-reduce of the flat buffer in two pieces, the first one overlapped with the rest of the backward.
 
     Parameters are laid out in module order: [view encoders (model[0]) | JointAttention + FC head].  Backward runs the
-    other way round, so the second slice (97 % of the bytes at the tuned Davis config) is final as soon as the
+    other way round, so the second slice (89 % of the bytes at the tuned Davis config) is final as soon as the
     gradient w.r.t. the encoders' outputs exists: a tensor hook on those outputs starts its all-reduce (async: RCCL
     runs it on its own stream, ordered behind the kernels enqueued so far) while the encoders' backward still runs;
     the small first slice follows after backward.  Same sums as one all-reduce of the whole buffer."""
