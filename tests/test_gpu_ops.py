@@ -384,6 +384,42 @@ def test_e2e_training_step_vs_reference_golden(device):
 
 
 # ------------------------------------------------------------------------------------------------ full sizes
+def test_overlapped_gradient_sync_on_rccl_single_rank(device):
+    """The data-parallel step's two-piece gradient all-reduce on the real backend (RCCL, one rank: sums are the
+    identity): the hook fires during backward, the asynchronous collective is ordered behind the kernels that wrote
+    its slice, and the gradients equal those of the plain step."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from jova_amd.train import OverlappedGradSync, Trainer, encoder_param_split
+    z, hp, hparams, net, batch = _e2e_setup(device)
+    tr = Trainer(net, hparams)
+    tr.flat.zero_grad()
+    loss, _ = tr.forward_loss(batch)
+    loss.backward()
+    want = tr.flat.grad.clone()
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    try:
+        split = encoder_param_split(net, tr.flat)
+        assert split is not None and 0 < split < tr.flat.numel
+        tr.sync = OverlappedGradSync(tr.flat, split, dist.group.WORLD)
+        tr.flat.zero_grad()
+        loss2, _ = tr.forward_loss(batch)
+        loss2.backward()
+        assert tr.sync.work is not None, "the hook on the encoders' outputs did not fire"
+        tr.sync.finish()
+        torch.cuda.synchronize()
+        # (float atomics in the split-K / dW kernels: two runs of the same step differ by a few 1e-6 of the scale)
+        assert float((tr.flat.grad - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    finally:
+        dist.destroy_process_group()
+
+
 def test_davis_full_size_step_vs_oracle(device):
     """BASELINE.json config 2: the tuned Davis model, B = 128, fwd+bwd on the GPU against the fp64 oracle run on the host
     with the same weights and the same batch (dropout off: its mask is RNG-specific).
