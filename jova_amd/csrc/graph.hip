@@ -518,8 +518,11 @@ struct DmaPass<KG, KG> {
     static __device__ __forceinline__ void run(const Buf&, int, int, int, int, const float4*, f32x16&) {}
 };
 
+#ifndef JOVA_FWD_WPE
+#define JOVA_FWD_WPE 2
+#endif
 template <int KG, int NPL>
-__global__ void __launch_bounds__(128, (NPL <= 4 ? 2 : 1))
+__global__ void __launch_bounds__(128, (NPL <= 4 ? JOVA_FWD_WPE : 1))
 graphconv_fwd_dma_kernel(const float* __restrict__ x, int n_atoms, int ldx, int f_out,
                          const long long* __restrict__ deg_slice, GcParams P, const float* __restrict__ wq, int ncb,
                          int relu, float* __restrict__ out, double* __restrict__ stats, int group, BwdPlan plan) {

@@ -19,7 +19,15 @@ for m in (conv1, conv2):
         prm.grad = torch.zeros_like(prm)
 x2 = torch.randn(n, 64, device=dev).relu_().requires_grad_(True)
 g64 = torch.randn(n, 64, device=dev)
-y1, y2 = conv1(glist), conv2([x2] + glist[1:])
+if "f80" in sys.argv:        # experiment: layer 1 with 80 real columns (aligned dW rows)
+    conv1 = GraphConvLayer(80, 64, activation=act).to(dev)
+    for prm in conv1.parameters():
+        prm.grad = torch.zeros_like(prm)
+    x80 = torch.randn(n, 80, device=dev)
+    y1 = conv1([x80] + glist[1:])
+    y2 = conv2([x2] + glist[1:])
+else:
+    y1, y2 = conv1(glist), conv2([x2] + glist[1:])
 which = [("l1", y1), ("l2", y2)]
 if "l1last" in sys.argv:
     which = which[::-1]
@@ -40,8 +48,8 @@ if os.environ.get("JOVA_LIB"):
     buf = (ctypes.c_ulonglong * (4096 * 8))()
     L.jova_debug_bwd_prof(buf, 4096 * 8)
     a = np.array(buf[:], dtype=np.uint64).reshape(4096, 8)
-    print("one WG (last writer): issue cycles %d, epilogue cycles %d (whole loop)" % (a[4095, 6], a[4095, 7]))
-    a = a[:4095]
+
+
     a = a[a[:, 6] > 0]
     t0 = a[:, 0].min()
     ent, ls, le, fl = [(a[:, k] - t0).astype(np.float64) / 100.0 for k in range(4)]
