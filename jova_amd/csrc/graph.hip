@@ -444,7 +444,7 @@ struct RowIdx {
             main[it] = 0;
             if (p >= p_begin && p < p_end) {
                 if (p == 0) main[it] = (int)(row0 + rc);
-                else main[it] = adj_d[(long long)(lrow0 + rc) * deg + nb0 + p - 1];
+                else main[it] = adj_d[__umul24((unsigned)(lrow0 + rc), (unsigned)deg) + (unsigned)(nb0 + p - 1)];
             }
         }
         if (KG > 8) {
@@ -455,7 +455,7 @@ struct RowIdx {
                 tail[p] = 0;
                 if (p >= p_begin && p < p_end) {
                     if (p == 0) tail[p] = (int)(row0 + rc);
-                    else tail[p] = adj_d[(long long)(lrow0 + rc) * deg + nb0 + p - 1];
+                    else tail[p] = adj_d[__umul24((unsigned)(lrow0 + rc), (unsigned)deg) + (unsigned)(nb0 + p - 1)];
                 }
             }
         }
@@ -472,7 +472,7 @@ struct RowIdx {
                 const int p = it >> 2;
                 const int sw = ((it & 1) * 8 + sub) & 15;        // slot & 15
                 if (p >= p_begin && p < p_end)
-                    glds16(x + (long long)min(max(main[it], 0), n_atoms - 1) * ldx + ((pos ^ sw) << 2),
+                    glds16(x + (__umul24(min((unsigned)main[it], (unsigned)(n_atoms - 1)), (unsigned)ldx) + ((pos ^ sw) << 2)),
                            buf.main(p) + ((it & 3) * 8 + wave * 4) * 64);
             }
         }
@@ -481,7 +481,7 @@ struct RowIdx {
 #pragma unroll
             for (int p = 0; p < NPL; ++p) {
                 if (p >= p_begin && p < p_end)
-                    glds16(x + (long long)min(max(tail[p], 0), n_atoms - 1) * ldx + 64 + ((pos ^ ((r >> 2) & 3)) << 2),
+                    glds16(x + (__umul24(min((unsigned)tail[p], (unsigned)(n_atoms - 1)), (unsigned)ldx) + 64 + ((pos ^ ((r >> 2) & 3)) << 2)),
                            buf.tail(p) + (wave * 16) * 16);
             }
         }
@@ -574,16 +574,22 @@ graphconv_fwd_dma_kernel(const float* __restrict__ x, int n_atoms, int ldx, int 
         idx.load(adj_d, deg, (tile0 + 1) * GT, bstart + (long long)(tile0 + 1) * GT, min(GT, bsize - (tile0 + 1) * GT),
                  0, 0, ppt, tid);
 
+    // (wave-uniform base + 32-bit lane offsets; full tiles store without per-row tests; fp64 statistics only on request)
     auto store_tile = [&](const f32x16& a, long long row0, int rows) {
+        if (!colok) return;
+        float* ob = out + row0 * f_out;
+        const unsigned fo = (unsigned)f_out, co = (unsigned)col;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = mfma32_row(r, lane);
+            const unsigned row = (unsigned)mfma32_row(r, lane);
             float v = a[r] + bias;
             if (relu) v = fmaxf(v, 0.f);
-            if (row < rows && colok) {
-                out[(row0 + row) * f_out + col] = v;
-                s += (double)v;
-                q += (double)v * (double)v;
+            if (rows == GT || (int)row < rows) {
+                ob[row * fo + co] = v;
+                if (stats) {
+                    s += (double)v;
+                    q += (double)v * (double)v;
+                }
             }
         }
     };
@@ -1807,8 +1813,10 @@ extern "C" int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t l
     // fast form: fp32 rows of 64 or 80 floats read whole by 16-byte LDS-DMA; columns f_in .. 8 kg - 1 of a row are
     // multiplied by zero weights, so they must exist (ld >= 8 kg) and hold finite values (the fp32 copy of int64
     // atoms is zero padded)
+    // (the kernel's addressing is 24 x 24-bit multiplies and 32-bit element offsets)
     if (!atoms_is_i64 && (kg == 8 || kg == 10) && ld_atoms >= 8 * kg && (ld_atoms & 3) == 0 &&
-        (((uintptr_t)atoms) & 15) == 0 && !getenv("JOVA_GRAPHCONV_NO_DMA")) {
+        n_atoms < (1 << 24) && n_atoms * ld_atoms < (1ll << 31) && (((uintptr_t)atoms) & 15) == 0 &&
+        !getenv("JOVA_GRAPHCONV_NO_DMA")) {
         const long long qtotal = 21ll * ncb * kg * 256;
         hipLaunchKernelGGL(graphconv_pack_dma_kernel, dim3(cdiv(qtotal, 256)), dim3(256), 0, s, P, f_in, f_out, kg, ncb,
                            packed_ws);
