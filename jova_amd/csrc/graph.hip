@@ -891,7 +891,7 @@ __device__ __forceinline__ void bwd_issue(const float* __restrict__ x, const flo
         }
 #pragma unroll
         for (int p = 0; p < CNT; ++p)
-            glds16(x + (long long)min(max(nidx[2 * p + it], 0), n_atoms - 1) * ldx + chunk,
+            glds16(x + (__umul24(min((unsigned)nidx[2 * p + it], (unsigned)(n_atoms - 1)), (unsigned)ldx) + chunk),
                    buf + (p + 1) * MAINF + base);
     }
     if (KG > 8 && wave < 2) {
@@ -902,7 +902,8 @@ __device__ __forceinline__ void bwd_issue(const float* __restrict__ x, const flo
         if (XOWN) glds16(x + (row0 + rc) * ldx + tchunk, xtail + base);
 #pragma unroll
         for (int p = 0; p < CNT; ++p)
-            glds16(x + (long long)min(max(tidx[p], 0), n_atoms - 1) * ldx + tchunk, xtail + (p + 1) * TAILF + base);
+            glds16(x + (__umul24(min((unsigned)tidx[p], (unsigned)(n_atoms - 1)), (unsigned)ldx) + tchunk),
+                   xtail + (p + 1) * TAILF + base);
     }
 }
 
@@ -1033,12 +1034,12 @@ graphconv_bwd_dma_kernel(const float* __restrict__ x, int n_atoms, int ldx, int 
             for (int it = 0; it < 2; ++it) {
                 const int r = it * 16 + sub;
                 const int rc = r < rows ? r : rows - 1;
-                nidx[2 * p + it] = adj_s[(long long)(lrow0 + rc) * deg + q];
+                nidx[2 * p + it] = adj_s[__umul24((unsigned)(lrow0 + rc), (unsigned)deg) + (unsigned)q];
             }
             if (KG > 8) {
                 const int r = (tid >> 2) & 31;
                 const int rc = r < rows ? r : rows - 1;
-                tidx[p] = adj_s[(long long)(lrow0 + rc) * deg + q];
+                tidx[p] = adj_s[__umul24((unsigned)(lrow0 + rc), (unsigned)deg) + (unsigned)q];
             }
         }
     };
@@ -1177,16 +1178,17 @@ graphconv_bwd_dma_kernel(const float* __restrict__ x, int n_atoms, int ldx, int 
             advance(st);
         }
         if (NEED_DX && rd == nrounds - 1 && (deg > 0 || wave >= 2)) {
-            float* dst = (wave < 2 ? gbuf : dx) + row0 * f_in + col2;
+            float* dst = (wave < 2 ? gbuf : dx) + row0 * f_in;        // wave-uniform base, 32-bit lane offsets
+            const unsigned fi = (unsigned)f_in, c2 = (unsigned)col2;
             if (col2 < f_in) {
                 if (rows == GT) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dst[(long long)mfma32_row(r, lane) * f_in] = g[r];
+                    for (int r = 0; r < 16; ++r) dst[(unsigned)mfma32_row(r, lane) * fi + c2] = g[r];
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = mfma32_row(r, lane);
-                        if (row < rows) dst[(long long)row * f_in] = g[r];
+                        if (row < rows) dst[(unsigned)row * fi + c2] = g[r];
                     }
                 }
             }
@@ -1895,6 +1897,7 @@ extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t l
     // fast form (see graphconv_bwd_dma_kernel): whole 256-byte rows by LDS-DMA; pad columns f_in .. 8 kg - 1 must exist
     // and hold finite values (their products are not stored)
     if (!atoms_is_i64 && f_out == 64 && (kg == 8 || kg == 10) && ld_atoms >= 8 * kg && (ld_atoms & 3) == 0 && al16 &&
+        n_atoms < (1 << 24) && n_atoms * ld_atoms < (1ll << 31) &&
         (!dx_or_null || (kg == 8 && (f_in & 3) == 0)) && !getenv("JOVA_GRAPHCONV_NO_DMA")) {
         const int tiles = cdiv(n_atoms, GT);
         int group = tiles > 2048 ? cdiv(tiles, 2000) : 1;
