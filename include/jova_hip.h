@@ -54,7 +54,11 @@ int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t ld_atoms, in
                        const int64_t* deg_slice, const int32_t* const* adj, const float* const* weight,
                        const float* dy, const float* y_or_null, float* const* dweight, float* const* dbias,
                        float* dx_or_null, float* gbuf_or_null, const int* sym_flag, const int64_t* deg_slice_host,
-                       void* stream);
+                       float* dw_scratch_or_null, void* stream);
+/* floats of the optional `dw_scratch` above: an aligned image of the 21 weight gradients that the kernel accumulates in
+ * when f_in is not a multiple of 32 (rows of 75 floats straddle 128-byte lines and slow the float atomics 10x);
+ * contents on entry are ignored, the result is added to dweight by a fold kernel. */
+size_t jova_graphconv_bwd_scratch_floats(void);
 
 /* *flag <- 1 iff the adjacency is a simple undirected graph (no self loops / duplicates, i in nbr(j) <=> j in nbr(i)):
  * then the backward scatters above and below run as gathers.  Always true for ConvMol bond graphs. */

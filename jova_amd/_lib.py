@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("JOVA_LIB") or os.path.join(_HERE, "libjova_hip.so")  
 _SIGS = {
     "jova_graphconv_fwd": "piqqiipppp" + "ippppp",
     "jova_atoms_to_f32": "pqiipp",
-    "jova_graphconv_bwd": "piqqiippp" + "pppp" + "ppppp",
+    "jova_graphconv_bwd": "piqqiippp" + "pppp" + "pppppp",
     "jova_adj_symmetry": "qpppp",
     "jova_graphpool_fwd": "pqipp" + "ppp",
     "jova_graphpool_bwd": "ppqipp" + "ppipp",
@@ -48,7 +48,7 @@ _SIGS = {
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "q": ctypes.c_int64, "f": ctypes.c_float, "Q": ctypes.c_uint64}
 
 EXPORTS = sorted(list(_SIGS) + ["jova_last_error", "jova_abi_version", "jova_nonsat_workspace_bytes",
-                                "jova_graphconv_workspace_floats"])
+                                "jova_graphconv_workspace_floats", "jova_graphconv_bwd_scratch_floats"])
 
 _lib = None
 
@@ -72,6 +72,8 @@ def lib():
         L.jova_nonsat_workspace_bytes.argtypes = [ctypes.c_int64]
         L.jova_graphconv_workspace_floats.restype = ctypes.c_size_t
         L.jova_graphconv_workspace_floats.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.jova_graphconv_bwd_scratch_floats.restype = ctypes.c_size_t
+        L.jova_graphconv_bwd_scratch_floats.argtypes = []
         _lib = L
     return _lib
 

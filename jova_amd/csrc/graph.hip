@@ -997,12 +997,22 @@ __device__ __forceinline__ void bwd_dw_round(const float* buf, bool first, int i
     }
 }
 
+#define DWP_LD 96          // row stride (floats) of the aligned scratch image of the 21 weight gradients [21][64][96]
+__global__ void graphconv_dw_fold_kernel(const float* __restrict__ dwp, GcGrads Gd, int f_in) {
+    const int total = 21 * 64 * f_in;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int k = e % f_in, wo = e / f_in;
+        const int o = wo & 63, w = wo >> 6;
+        Gd.dw[w][o * f_in + k] += dwp[(long long)wo * DWP_LD + k];
+    }
+}
+
 template <int KG, bool NEED_DX, bool MASK, int NBP, bool DB>
 __global__ void __launch_bounds__(256, 2)
 graphconv_bwd_dma_kernel(const float* __restrict__ x, int n_atoms, int ldx, int f_in,
                          const long long* __restrict__ deg_slice, GcParams P, const float* __restrict__ dy,
                          const float* __restrict__ y, GcGrads Gd, float* __restrict__ gbuf, float* __restrict__ dx,
-                         int group, BwdPlan plan) {
+                         int group, BwdPlan plan, float* __restrict__ dwp) {
     constexpr int MAINF = GT * 64, TAILF = GT * 16;
     constexpr int BUFF = (2 + NBP + (MASK ? 1 : 0)) * MAINF + (KG > 8 ? (1 + NBP) * TAILF : 0);
     __shared__ __attribute__((aligned(16))) float lds[(DB ? 2 : 1) * BUFF];
@@ -1208,17 +1218,24 @@ graphconv_bwd_dma_kernel(const float* __restrict__ x, int n_atoms, int ldx, int 
             if (deg > 0) atomicAdd(&Gd.db[w_rel][32 * ot + i], db_acc);
         }
     }
+    // Rows of f_in = 75 floats put every 32-float run of a weight row across two or three 128-byte lines, and the
+    // float atomics of ~500 workgroups on such runs took 21 us of the 127 us at 75 -> 64 (13 us with 80-float rows,
+    // 2 us with 64-float rows): with a scratch image whose rows are DWP_LD = 96 floats every run is one aligned
+    // line; graphconv_dw_fold_kernel adds the image to the real gradients afterwards.
+    float* const ws = dwp ? dwp + (long long)w_self * 64 * DWP_LD : Gd.dw[w_self];
+    float* const wr = dwp ? dwp + (long long)w_rel * 64 * DWP_LD : Gd.dw[w_rel];
+    const int ldw = dwp ? DWP_LD : f_in;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int o = 32 * ot + mfma32_row(r, lane);
         const int k = 32 * kt + i;
         if (k < f_in) {
-            atomicAdd(&Gd.dw[w_self][o * f_in + k], a_self[r]);
-            if (deg > 0) atomicAdd(&Gd.dw[w_rel][o * f_in + k], a_rel[r]);
+            atomicAdd(&ws[o * ldw + k], a_self[r]);
+            if (deg > 0) atomicAdd(&wr[o * ldw + k], a_rel[r]);
         }
         if (KG > 8 && i < 16 && 64 + i < f_in) {
-            atomicAdd(&Gd.dw[w_self][o * f_in + 64 + i], t_self[r]);
-            if (deg > 0) atomicAdd(&Gd.dw[w_rel][o * f_in + 64 + i], t_rel[r]);
+            atomicAdd(&ws[o * ldw + 64 + i], t_self[r]);
+            if (deg > 0) atomicAdd(&wr[o * ldw + 64 + i], t_rel[r]);
         }
     }
 #ifdef JOVA_BWD_PROFILE
@@ -1785,6 +1802,8 @@ extern "C" size_t jova_graphconv_workspace_floats(int f_in, int f_out) {
     return a > b ? a : b;
 }
 
+extern "C" size_t jova_graphconv_bwd_scratch_floats(void) { return (size_t)21 * 64 * DWP_LD; }
+
 extern "C" int jova_atoms_to_f32(const int64_t* atoms, int64_t n_atoms, int f, int ld, float* out, void* stream) {
     JOVA_CHECK_ARG(atoms && out && n_atoms >= 0 && f >= 1 && ld >= f, "atoms_to_f32: bad argument");
     if (n_atoms == 0) return JOVA_OK;
@@ -1878,7 +1897,8 @@ extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t l
                                   int f_out, const int64_t* deg_slice, const int32_t* const* adj,
                                   const float* const* weight, const float* dy, const float* y_or_null,
                                   float* const* dweight, float* const* dbias, float* dx_or_null, float* gbuf_or_null,
-                                  const int* sym_flag, const int64_t* deg_slice_host, void* stream) {
+                                  const int* sym_flag, const int64_t* deg_slice_host, float* dw_scratch_or_null,
+                                  void* stream) {
     JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 31), "graphconv_bwd: n_atoms out of range");
     JOVA_CHECK_ARG(f_in >= 1 && f_in <= 128, "graphconv_bwd: f_in %d not in [1,128]", f_in);
     JOVA_CHECK_ARG(f_out >= 1 && f_out <= 64, "graphconv_bwd: f_out %d not in [1,64]", f_out);
@@ -1909,6 +1929,9 @@ extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t l
         const bool nodb = getenv("JOVA_BWD_DB") == nullptr;
         const bool db = !y_or_null && !nodb;
         const int nbp = db ? (kg == 8 ? 3 : 2) : 4;
+        // weight rows that are not whole 128-byte lines: accumulate in the aligned scratch image, fold afterwards
+        float* dwp = (dw_scratch_or_null && (f_in & 31) != 0 && !getenv("JOVA_BWD_NO_DWP")) ? dw_scratch_or_null : nullptr;
+        if (dwp) JOVA_CHECK_HIP(hipMemsetAsync(dwp, 0, sizeof(float) * 21 * 64 * DWP_LD, s));
         BwdPlan plan;
         memset(&plan, 0, sizeof(plan));
         if (deg_slice_host && !getenv("JOVA_BWD_NOPLAN")) {
@@ -1919,7 +1942,7 @@ extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t l
 #define GC_BWD_DMA(KG_, DX_, M_, NBP_, DB_)                                                                            \
     hipLaunchKernelGGL((graphconv_bwd_dma_kernel<KG_, DX_, M_, NBP_, DB_>), grid, dim3(256), 0, s, (const float*)atoms,\
                        (int)n_atoms, (int)ld_atoms, f_in, (const long long*)deg_slice, P, dy, y_or_null, G,            \
-                       gbuf_or_null, dx_or_null, group, plan)
+                       gbuf_or_null, dx_or_null, group, plan, dwp)
         // dZ handed in (the consumer BatchNorm applied the ReLU mask): two LDS buffers of [own, dZ, 3 (2) neighbour
         // planes] fit two workgroups per CU; with the Y plane only the single-buffer form does
         if (dx_or_null) {
@@ -1934,6 +1957,10 @@ extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t l
         }
 #undef GC_BWD_DMA
         JOVA_CHECK_LAUNCH("graphconv_bwd_dma");
+        if (dwp) {
+            hipLaunchKernelGGL(graphconv_dw_fold_kernel, dim3(cdiv(21 * 64 * f_in, 256)), dim3(256), 0, s, dwp, G, f_in);
+            JOVA_CHECK_LAUNCH("graphconv_dw_fold");
+        }
         if (dx_or_null) {
             JOVA_CHECK_ARG(sym_flag, "graphconv_bwd: sym_flag is null");
             hipLaunchKernelGGL(graphconv_bwd_dx_v4_kernel, dim3(cdiv(n_atoms, 16)), dim3(256), 0, s, (int)n_atoms, f_in,

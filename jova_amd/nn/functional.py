@@ -183,12 +183,13 @@ class GraphConvFunction(torch.autograd.Function):
         need_dx = (not ctx.is_i64) and ctx.needs_input_grad[0]
         dx = _empty((n, f_in), out) if need_dx else None
         gbuf = _empty((n, f_in), out) if need_dx else None
+        dws = _empty((int(_lib.lib().jova_graphconv_bwd_scratch_floats()),), out) if f_in % 32 else None
         # (a BatchNorm that consumes this layer's ReLU output applies the ReLU backward itself: mask_fused)
         mask = ctx.relu and not getattr(ctx, "mask_fused", False)
         call("jova_graphconv_bwd", P(xf), 0, ld, n, f_in, f_out, P(topo.deg_slice), topo.adj_ptrs,
              ptr_array(ctx.weights), P(dy), P(out) if mask else None, ptr_array(sink.targets[:21]),
              ptr_array(sink.targets[21:]), P(dx), P(gbuf), P(topo.sym_flag),
-             ctypes.c_void_p(topo.deg_slice_host.ctypes.data), stream())
+             ctypes.c_void_p(topo.deg_slice_host.ctypes.data), P(dws), stream())
         return (dx, None, None, None) + tuple(sink.returns)
 
 
