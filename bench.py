@@ -206,6 +206,28 @@ def graph_stress(device, reps=20, full=True):
         timed("graphpool_bwd(64)", lambda: call("jova_graphpool_bwd", P(dz), P(arg), n, 64, ds, adj, P(dx),
                                                 P(topo.sym_flag), sym, P(topo.rev_pos), st),
               4 * (2 * n * 64 + e) + n * 64, kernels=("graphpool_bwd_v5_kernel",))
+    if full:
+        # GraphGather2D (contiguous chunks -> zero-padded [A_max, B, g]) and the nonsat activation on it, g = 128
+        g = 128
+        lst = topo.n_atoms_lst
+        a_max, bsz = max(lst), len(lst)
+        xg = torch.randn(n, g, device=device)
+        og = torch.empty(a_max, bsz, g, device=device)
+        dxg = torch.zeros(n, g, device=device)
+        timed("gather2d_fwd(g=128)", lambda: call("jova_gather2d_fwd", P(xg), P(topo.mol_off), a_max, bsz, g, P(og), st),
+              4 * (n * g + a_max * bsz * g))
+        timed("gather2d_bwd(g=128)", lambda: call("jova_gather2d_bwd", P(og), P(topo.mol_off), a_max, bsz, g, P(dxg), st),
+              4 * (2 * n * g))
+        ne = og.numel()
+        on, df = torch.empty_like(og), torch.empty_like(og)
+        nev = torch.empty(3, dtype=torch.int32, device=device)
+        wsn = torch.empty(int(lib().jova_nonsat_workspace_bytes(ne)), dtype=torch.uint8, device=device)
+        call("jova_nonsat_fwd", P(og), ne, 1e-4, 100, P(on), P(df), P(nev), P(wsn), st)
+        evals = int(nev[0].item())
+        # per evaluation: read x and y, write y' (12 B / element); final pass: read 2, write 2 (16 B / element)
+        timed("nonsat_fwd(%d evaluations, one persistent launch)" % evals,
+              lambda: call("jova_nonsat_fwd", P(og), ne, 1e-4, 100, P(on), P(df), P(nev), P(wsn), st),
+              ne * (12 * evals + 16), launches=3)
     return dict(workload="graph4k: 4096 molecules, %d atoms, %d directed edges" % (n, e), kernels=res,
                 note="kernel durations: reps launches through the C ABI between two HIP events; fwd = weight re-pack + "
                      "kernel; conv backward takes dZ (ReLU mask applied by the BatchNorm backward, as in the model)")

@@ -1643,6 +1643,35 @@ __global__ void gather2d_bwd_kernel(const float* __restrict__ dout, const int* _
     if (a < n) dx[(long long)(o + a) * g + c] = dout[e];
 }
 
+// float4 forms (g % 4 == 0, 16-byte aligned): one thread per 16 bytes of the padded tensor, one division per 16 bytes
+__global__ void __launch_bounds__(256)
+gather2d_fwd_v4_kernel(const float* __restrict__ x, const int* __restrict__ mol_off, int a_max, int bsz, int g4,
+                       float* __restrict__ out) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // float4 index
+    const long long total = (long long)a_max * bsz * g4;
+    if (e >= total) return;
+    const unsigned ab = (unsigned)(e / g4);
+    const int c = (int)(e - (long long)ab * g4);
+    const int a = (int)(ab / (unsigned)bsz), b = (int)(ab - (unsigned)a * (unsigned)bsz);
+    const int o = mol_off[b], n = mol_off[b + 1] - o;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a < n) v = reinterpret_cast<const float4*>(x)[(long long)(o + a) * g4 + c];
+    reinterpret_cast<float4*>(out)[e] = v;
+}
+
+__global__ void __launch_bounds__(256)
+gather2d_bwd_v4_kernel(const float* __restrict__ dout, const int* __restrict__ mol_off, int a_max, int bsz, int g4,
+                       float* __restrict__ dx) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)a_max * bsz * g4;
+    if (e >= total) return;
+    const unsigned ab = (unsigned)(e / g4);
+    const int c = (int)(e - (long long)ab * g4);
+    const int a = (int)(ab / (unsigned)bsz), b = (int)(ab - (unsigned)a * (unsigned)bsz);
+    const int o = mol_off[b], n = mol_off[b + 1] - o;
+    if (a < n) reinterpret_cast<float4*>(dx)[(long long)(o + a) * g4 + c] = reinterpret_cast<const float4*>(dout)[e];
+}
+
 // ------------------------------------------------------------------------------------------------ nonsat
 // y <- x; repeat y' = (2 y^3 / 3 + x) / (y^2 + 1) until mean|y' - y| <= ep or the evaluation index exceeds
 // max_iter (reference jova/nn/models.py:458-478).  The stop rule is a GLOBAL mean over the padded tensor, so the
@@ -1654,6 +1683,9 @@ __global__ void gather2d_bwd_kernel(const float* __restrict__ dout, const int* _
 // ctrl[0] = evaluations done, ctrl[1] = arrival counter, ctrl[2] = timeout flag.
 #define NS_MAX_BLOCKS 512
 #define NS_THREADS 1024
+// VEC = 4: every access is 16 bytes (n % 4 == 0, 16-byte aligned buffers); element order inside the sums differs from
+// VEC = 1 only in which lane adds which element - the per-workgroup partials are fp64 and combined in a fixed order.
+template <int VEC>
 __global__ void __launch_bounds__(NS_THREADS)
 nonsat_persistent_kernel(const float* __restrict__ x, float* __restrict__ ya, float* __restrict__ yb, long long n,
                          float ep, int max_iter, double* partial, int* ctrl, float* __restrict__ out,
@@ -1662,19 +1694,30 @@ nonsat_persistent_kernel(const float* __restrict__ x, float* __restrict__ ya, fl
     __shared__ int s_flag;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nb = gridDim.x;
-    const long long stride = (long long)nb * NS_THREADS;
-    const long long e0 = (long long)blockIdx.x * NS_THREADS + tid;
+    const long long stride = (long long)nb * NS_THREADS * VEC;
+    const long long e0 = ((long long)blockIdx.x * NS_THREADS + tid) * VEC;
     int evals = 0;
     for (int it = 0;; ++it) {
         const float* yin = (it & 1) ? yb : ya;
         float* yout = (it & 1) ? ya : yb;
         double acc = 0.0;
         for (long long e = e0; e < n; e += stride) {
-            const float xv = x[e];
-            const float y = it == 0 ? xv : yin[e];
-            const float yn = (2.f * (y * y * y) / 3.f + xv) / (y * y + 1.f);
-            yout[e] = yn;
-            acc += (double)fabsf(yn - y);
+            float xv[VEC], y[VEC], yn[VEC];
+            if (VEC == 4) {
+                *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + e);
+                if (it == 0) *reinterpret_cast<float4*>(y) = *reinterpret_cast<const float4*>(xv);
+                else *reinterpret_cast<float4*>(y) = *reinterpret_cast<const float4*>(yin + e);
+            } else {
+                xv[0] = x[e];
+                y[0] = it == 0 ? xv[0] : yin[e];
+            }
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) {
+                yn[u] = (2.f * (y[u] * y[u] * y[u]) / 3.f + xv[u]) / (y[u] * y[u] + 1.f);
+                acc += (double)fabsf(yn[u] - y[u]);       // every |delta| enters the fp64 sum on its own, as before
+            }
+            if (VEC == 4) *reinterpret_cast<float4*>(yout + e) = *reinterpret_cast<const float4*>(yn);
+            else yout[e] = yn[0];
         }
         acc = wave_sum_d(acc);
         if (lane == 0) red[wave] = acc;
@@ -1721,9 +1764,17 @@ nonsat_persistent_kernel(const float* __restrict__ x, float* __restrict__ ya, fl
     const float* yr = res_in_b ? yb : ya;
     const float* yp = evals == 1 ? x : (res_in_b ? ya : yb);
     for (long long e = e0; e < n; e += stride) {
-        const float pv = yp[e];
-        out[e] = yr[e];
-        dfac[e] = 1.f / (pv * pv + 1.f);      // d y_final / d x (gradient flows through the last evaluation only)
+        // d y_final / d x = 1 / (y_prev^2 + 1): the gradient flows through the last evaluation only
+        if (VEC == 4) {
+            const float4 pv = *reinterpret_cast<const float4*>(yp + e);
+            *reinterpret_cast<float4*>(out + e) = *reinterpret_cast<const float4*>(yr + e);
+            *reinterpret_cast<float4*>(dfac + e) = make_float4(1.f / (pv.x * pv.x + 1.f), 1.f / (pv.y * pv.y + 1.f),
+                                                               1.f / (pv.z * pv.z + 1.f), 1.f / (pv.w * pv.w + 1.f));
+        } else {
+            const float pv = yp[e];
+            out[e] = yr[e];
+            dfac[e] = 1.f / (pv * pv + 1.f);
+        }
     }
 }
 
@@ -2068,8 +2119,12 @@ extern "C" int jova_gather2d_fwd(const float* x, const int32_t* mol_off, int a_m
     JOVA_CHECK_ARG(x && mol_off && out && a_max >= 0 && batch >= 1 && g >= 1, "gather2d_fwd: bad argument");
     const long long total = (long long)a_max * batch * g;
     if (total == 0) return JOVA_OK;
-    hipLaunchKernelGGL(gather2d_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, mol_off,
-                       a_max, batch, g, out);
+    if ((g & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0 && (long long)a_max * batch < (1ll << 32))
+        hipLaunchKernelGGL(gather2d_fwd_v4_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                           mol_off, a_max, batch, g / 4, out);
+    else
+        hipLaunchKernelGGL(gather2d_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, mol_off,
+                           a_max, batch, g, out);
     JOVA_CHECK_LAUNCH("gather2d_fwd");
     return JOVA_OK;
 }
@@ -2079,8 +2134,12 @@ extern "C" int jova_gather2d_bwd(const float* dout, const int32_t* mol_off, int 
     JOVA_CHECK_ARG(dout && mol_off && dx && a_max >= 0 && batch >= 1 && g >= 1, "gather2d_bwd: bad argument");
     const long long total = (long long)a_max * batch * g;
     if (total == 0) return JOVA_OK;
-    hipLaunchKernelGGL(gather2d_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, mol_off,
-                       a_max, batch, g, dx);
+    if ((g & 3) == 0 && ((((uintptr_t)dout) | ((uintptr_t)dx)) & 15) == 0 && (long long)a_max * batch < (1ll << 32))
+        hipLaunchKernelGGL(gather2d_bwd_v4_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, dout,
+                           mol_off, a_max, batch, g / 4, dx);
+    else
+        hipLaunchKernelGGL(gather2d_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, mol_off,
+                           a_max, batch, g, dx);
     JOVA_CHECK_LAUNCH("gather2d_bwd");
     return JOVA_OK;
 }
@@ -2103,11 +2162,17 @@ extern "C" int jova_nonsat_fwd(const float* x, int64_t n, float ep, int max_iter
     JOVA_CHECK_HIP(hipMemsetAsync(workspace, 0, 64 + sizeof(double) * 2 * NS_MAX_BLOCKS, s));
     if (n == 0) return JOVA_OK;
     // one workgroup per CU at most: every workgroup is resident, which the in-kernel barrier needs
-    int blocks = (int)((n + NS_THREADS - 1) / NS_THREADS);
+    const bool vec4 = (n & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)out) | ((uintptr_t)dfac) | ((uintptr_t)ya)) & 15) == 0;
+    const long long per_block = (long long)NS_THREADS * (vec4 ? 4 : 1);
+    int blocks = (int)((n + per_block - 1) / per_block);
     const int cap = g_num_cu < NS_MAX_BLOCKS ? g_num_cu : NS_MAX_BLOCKS;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(nonsat_persistent_kernel, dim3(blocks), dim3(NS_THREADS), 0, s, x, ya, yb, (long long)n, ep,
-                       max_iter, partial, ctrl, out, dfac);
+    if (vec4)
+        hipLaunchKernelGGL(nonsat_persistent_kernel<4>, dim3(blocks), dim3(NS_THREADS), 0, s, x, ya, yb, (long long)n, ep,
+                           max_iter, partial, ctrl, out, dfac);
+    else
+        hipLaunchKernelGGL(nonsat_persistent_kernel<1>, dim3(blocks), dim3(NS_THREADS), 0, s, x, ya, yb, (long long)n, ep,
+                           max_iter, partial, ctrl, out, dfac);
     JOVA_CHECK_LAUNCH("nonsat_persistent");
     JOVA_CHECK_HIP(hipMemcpyAsync(n_eval_dev, ctrl, 3 * sizeof(int), hipMemcpyDeviceToDevice, s));
     return JOVA_OK;
