@@ -66,6 +66,67 @@ __global__ void viewpool_fwd_kernel(const float* __restrict__ x, const int* __re
     out[t] = (float)s;
 }
 
+// float4 form (l % 4 == 0): a workgroup owns (b, v) and 128 columns; its 8 thread groups take every 8th segment of the
+// view (fp64 partial sums), the partials are added in group order through LDS.
+__global__ void __launch_bounds__(256)
+viewpool_fwd_v4_kernel(const float* __restrict__ x, const int* __restrict__ seg_off, int n_views, int bsz, int l,
+                       float* __restrict__ out) {
+    __shared__ double part[8][128];
+    const int cblocks = (l + 127) / 128;
+    const int cbk = blockIdx.x % cblocks;
+    const int bv = blockIdx.x / cblocks;
+    const int v = bv % n_views, b = bv / n_views;
+    const int q = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c = cbk * 128 + 4 * q;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (c < l) {
+        const int s_end = seg_off[v + 1];
+        const float* xp = x + (long long)b * l + c;
+        const long long sstride = (long long)bsz * l;
+        int sgm = seg_off[v] + grp;
+        for (; sgm + 24 < s_end; sgm += 32) {          // four segments of this group in flight
+            const float4 a0 = *reinterpret_cast<const float4*>(xp + sgm * sstride);
+            const float4 a1 = *reinterpret_cast<const float4*>(xp + (sgm + 8) * sstride);
+            const float4 a2 = *reinterpret_cast<const float4*>(xp + (sgm + 16) * sstride);
+            const float4 a3 = *reinterpret_cast<const float4*>(xp + (sgm + 24) * sstride);
+            s0 += (double)a0.x; s1 += (double)a0.y; s2 += (double)a0.z; s3 += (double)a0.w;
+            s0 += (double)a1.x; s1 += (double)a1.y; s2 += (double)a1.z; s3 += (double)a1.w;
+            s0 += (double)a2.x; s1 += (double)a2.y; s2 += (double)a2.z; s3 += (double)a2.w;
+            s0 += (double)a3.x; s1 += (double)a3.y; s2 += (double)a3.z; s3 += (double)a3.w;
+        }
+        for (; sgm < s_end; sgm += 8) {
+            const float4 a0 = *reinterpret_cast<const float4*>(xp + sgm * sstride);
+            s0 += (double)a0.x; s1 += (double)a0.y; s2 += (double)a0.z; s3 += (double)a0.w;
+        }
+    }
+    part[grp][4 * q + 0] = s0; part[grp][4 * q + 1] = s1; part[grp][4 * q + 2] = s2; part[grp][4 * q + 3] = s3;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int cc = cbk * 128 + threadIdx.x;
+        if (cc < l) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += part[k][threadIdx.x];
+            out[((long long)b * n_views + v) * l + cc] = (float)t;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+viewpool_bwd_v4_kernel(const float* __restrict__ dout, const int* __restrict__ seg_off, int n_views, int bsz, int l4,
+                       int s_total, float* __restrict__ dx) {
+    const long long total = (long long)s_total * bsz * l4;        // float4s
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const unsigned sb = (unsigned)(t / l4);
+        const int c = (int)(t - (long long)sb * l4);
+        const int sgm = (int)(sb / (unsigned)bsz), b = (int)(sb - (unsigned)sgm * (unsigned)bsz);
+        int v = 0;
+        for (int k = 1; k < n_views; ++k) v += (sgm >= seg_off[k]);
+        reinterpret_cast<float4*>(dx)[t] = reinterpret_cast<const float4*>(dout)[((long long)b * n_views + v) * l4 + c];
+    }
+}
+
 __global__ void viewpool_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ seg_off, int n_views,
                                     int bsz, int l, int s_total, float* __restrict__ dx) {
     const long long total = (long long)s_total * bsz * l;
@@ -177,8 +238,12 @@ extern "C" int jova_viewpool_fwd(const float* x, const int32_t* seg_off, int n_v
                                  void* stream) {
     JOVA_CHECK_ARG(x && seg_off && out && n_views >= 1 && batch >= 1 && l >= 1, "viewpool_fwd: bad argument");
     const long long total = (long long)batch * n_views * l;
-    hipLaunchKernelGGL(viewpool_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, seg_off,
-                       n_views, batch, l, out);
+    if ((l & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0)
+        hipLaunchKernelGGL(viewpool_fwd_v4_kernel, dim3(batch * n_views * ((l + 127) / 128)), dim3(256), 0,
+                           (hipStream_t)stream, x, seg_off, n_views, batch, l, out);
+    else
+        hipLaunchKernelGGL(viewpool_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, seg_off,
+                           n_views, batch, l, out);
     JOVA_CHECK_LAUNCH("viewpool_fwd");
     return JOVA_OK;
 }
@@ -188,8 +253,12 @@ extern "C" int jova_viewpool_bwd(const float* dout, const int32_t* seg_off, int 
     JOVA_CHECK_ARG(dout && seg_off && dx && n_views >= 1 && batch >= 1 && l >= 1 && s_total >= 0, "viewpool_bwd: bad argument");
     const long long total = (long long)s_total * batch * l;
     if (total == 0) return JOVA_OK;
-    hipLaunchKernelGGL(viewpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dout, seg_off,
-                       n_views, batch, l, s_total, dx);
+    if ((l & 3) == 0 && ((((uintptr_t)dout) | ((uintptr_t)dx)) & 15) == 0 && (long long)s_total * batch < (1ll << 32))
+        hipLaunchKernelGGL(viewpool_bwd_v4_kernel, dim3(ew_blocks(total / 4)), dim3(256), 0, (hipStream_t)stream, dout,
+                           seg_off, n_views, batch, l / 4, s_total, dx);
+    else
+        hipLaunchKernelGGL(viewpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dout, seg_off,
+                           n_views, batch, l, s_total, dx);
     JOVA_CHECK_LAUNCH("viewpool_bwd");
     return JOVA_OK;
 }

@@ -338,6 +338,30 @@ __global__ void dropout_kernel(const float* __restrict__ x, long long n_rows, in
     }
 }
 
+// Rows padded to a multiple of four floats (the attention probabilities: ld = S rounded up) and 16-byte aligned: the
+// padded tensor is one flat run of float4s, no division, 16-byte accesses; the pad columns are scaled / zeroed along
+// (nobody reads them).  The element -> random number map differs from the generic kernel's; forward and backward of
+// one dropout always take the same kernel (same shape), which is all that has to agree.
+__global__ void __launch_bounds__(256)
+dropout_v4_kernel(const float* __restrict__ x, long long quads, float p, unsigned long long seed,
+                  unsigned long long offset, float* __restrict__ y) {
+    const float scale = 1.f / (1.f - p);
+    for (long long qd = (long long)blockIdx.x * blockDim.x + threadIdx.x; qd < quads;
+         qd += (long long)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[qd];
+        const uint4 rnd = philox4x32_10(make_uint4((unsigned)qd, (unsigned)(qd >> 32), (unsigned)offset,
+                                                   (unsigned)(offset >> 32)),
+                                        make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+        const float k = 1.f / 16777216.f;
+        float4 o;
+        o.x = (float)(rnd.x >> 8) * k >= p ? v.x * scale : 0.f;
+        o.y = (float)(rnd.y >> 8) * k >= p ? v.y * scale : 0.f;
+        o.z = (float)(rnd.z >> 8) * k >= p ? v.z * scale : 0.f;
+        o.w = (float)(rnd.w >> 8) * k >= p ? v.w * scale : 0.f;
+        reinterpret_cast<float4*>(y)[qd] = o;
+    }
+}
+
 // ================================================================================================ C ABI
 extern "C" int jova_colstats(const float* x, int64_t n_rows, int c, double* stats, void* stream) {
     JOVA_CHECK_ARG(x && stats && n_rows >= 0 && c >= 1, "colstats: bad argument");
@@ -466,6 +490,14 @@ extern "C" int jova_dropout(const float* x, int64_t n_rows, int n, int64_t ld, f
     JOVA_CHECK_ARG(x && y && n_rows >= 0 && n >= 1 && ld >= n, "dropout: bad argument");
     JOVA_CHECK_ARG(p >= 0.f && p < 1.f, "dropout: p %f not in [0,1)", (double)p);
     if (n_rows == 0) return JOVA_OK;
+    if ((ld & 3) == 0 && ld - n < 4 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {
+        const long long q4 = n_rows * ld / 4;
+        const int b4 = (int)((q4 + 255) / 256 < 16384 ? (q4 + 255) / 256 : 16384);
+        hipLaunchKernelGGL(dropout_v4_kernel, dim3(b4), dim3(256), 0, (hipStream_t)stream, x, q4, p,
+                           (unsigned long long)seed, (unsigned long long)offset, y);
+        JOVA_CHECK_LAUNCH("dropout_v4");
+        return JOVA_OK;
+    }
     const long long quads = (n_rows * n + 3) / 4;
     const int blocks = (int)((quads + 255) / 256 < 8192 ? (quads + 255) / 256 : 8192);
     hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)n_rows, n,
