@@ -197,7 +197,7 @@ def graph_stress(device, reps=20, full=True):
               lambda: call("jova_graphconv_bwd", P(x1), 0, x1.shape[1], n, 75, 64, ds, adj, pw1, P(dz), None, pdw1, pdb1,
                            None, None, P(topo.sym_flag), dsh, P(dws), st),
               4 * (n * 64 + n * 75 + e) + 2 * 4 * 21 * 76 * 64,
-              kernels=("graphconv_bwd_dma_kernel<10, false, false, 4, false>",))
+              kernels=("graphconv_bwd_dma_kernel<10, false, false, 4, false>", "graphconv_dw_fold_kernel"), launches=3)
         timed("graphconv_bwd_l2(dW + dX, 2 launches)",
               lambda: call("jova_graphconv_bwd", P(x2), 0, 64, n, 64, 64, ds, adj, pw2, P(dz), None, pdw2, pdb2, P(dx),
                            P(gbuf), P(topo.sym_flag), dsh, None, st),
@@ -215,9 +215,9 @@ def graph_stress(device, reps=20, full=True):
         og = torch.empty(a_max, bsz, g, device=device)
         dxg = torch.zeros(n, g, device=device)
         timed("gather2d_fwd(g=128)", lambda: call("jova_gather2d_fwd", P(xg), P(topo.mol_off), a_max, bsz, g, P(og), st),
-              4 * (n * g + a_max * bsz * g))
+              4 * (n * g + a_max * bsz * g), kernels=("gather2d_fwd_v4_kernel",))
         timed("gather2d_bwd(g=128)", lambda: call("jova_gather2d_bwd", P(og), P(topo.mol_off), a_max, bsz, g, P(dxg), st),
-              4 * (2 * n * g))
+              4 * (2 * n * g), kernels=("gather2d_bwd_v4_kernel",))
         ne = og.numel()
         on, df = torch.empty_like(og), torch.empty_like(og)
         nev = torch.empty(3, dtype=torch.int32, device=device)
@@ -227,7 +227,7 @@ def graph_stress(device, reps=20, full=True):
         # per evaluation: read x and y, write y' (12 B / element); final pass: read 2, write 2 (16 B / element)
         timed("nonsat_fwd(%d evaluations, one persistent launch)" % evals,
               lambda: call("jova_nonsat_fwd", P(og), ne, 1e-4, 100, P(on), P(df), P(nev), P(wsn), st),
-              ne * (12 * evals + 16), launches=3)
+              ne * (12 * evals + 16), launches=3, kernels=("nonsat_persistent_kernel<4>",))
     return dict(workload="graph4k: 4096 molecules, %d atoms, %d directed edges" % (n, e), kernels=res,
                 note="kernel durations: reps launches through the C ABI between two HIP events; fwd = weight re-pack + "
                      "kernel; conv backward takes dZ (ReLU mask applied by the BatchNorm backward, as in the model)")
