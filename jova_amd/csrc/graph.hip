@@ -311,27 +311,8 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-__device__ __forceinline__ bool locate_tiles_desc(const long long* __restrict__ deg_slice, int blk, int group,
-                                                  int& deg, long long& bstart, int& bsize, int& tile0, int& ntile) {
-    for (int d = NB - 1; d >= 0; --d) {
-        const int size = (int)deg_slice[2 * d + 1];
-        const int tiles = (size + GT - 1) / GT;
-        const int groups = (tiles + group - 1) / group;
-        if (blk < groups) {
-            deg = d;
-            bstart = deg_slice[2 * d];
-            bsize = size;
-            tile0 = blk * group;
-            ntile = min(group, tiles - tile0);
-            return true;
-        }
-        blk -= groups;
-    }
-    return false;
-}
-
 // (start, size) of every bucket with ONE batch of scalar loads, then the workgroup's bucket by selects: the dependent
-// load-compare-branch chain of locate_tiles_desc costs a memory round trip per bucket (3 us of a workgroup's life).
+// load-compare-branch chain of a per-bucket loop costs a memory round trip per bucket (3 us of a workgroup's life).
 __device__ __forceinline__ bool locate_tiles_batch(const long long* __restrict__ deg_slice, int blk, int group, int& deg,
                                                    long long& bstart, int& bsize, int& tile0, int& ntile) {
     long long ds[2 * NB];
