@@ -73,7 +73,9 @@ static inline void colreduce_grid(long long n_rows, int c, dim3& grid, int& rpb)
     const int cb = cdiv(c, 64);
     int rb = (int)(2048 / cb);
     if (rb < 1) rb = 1;
-    long long want = (n_rows + 255) / 256;
+    // at least 16 rows per workgroup (4 row lanes x 4 rows in flight); small tensors (the [N atoms, 64] BatchNorms of the
+    // graph stack) then spread over ~n_rows / 16 workgroups instead of 16 workgroups walking 256 rows each (32 us)
+    long long want = (n_rows + 15) / 16;
     if (want < 1) want = 1;
     if (rb > want) rb = (int)want;
     rpb = (int)((n_rows + rb - 1) / rb);
