@@ -147,8 +147,47 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // One wave per row.  y = LN(x + r) * gamma + beta; saves mean / rstd per row.  Row length d <= 64 * LN_MAXV.
+// VEC4 (d % 4 == 0, 16-byte aligned rows): lane l owns columns 4 l + 256 k .. + 3 and moves them as float4.
 #define LN_MAXV 32
-template <int LNV>
+template <int LNV, bool VEC4>
+__device__ __forceinline__ int ln_col(int lane, int k) { return VEC4 ? 4 * lane + 256 * (k >> 2) + (k & 3) : lane + 64 * k; }
+
+template <int LNV, bool VEC4>
+__device__ __forceinline__ void ln_load(const float* __restrict__ p, int d, int lane, float* v) {
+    if (VEC4) {
+#pragma unroll
+        for (int k4 = 0; k4 < LNV / 4; ++k4) {
+            const int c = 4 * lane + 256 * k4;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < d) t = *reinterpret_cast<const float4*>(p + c);
+            v[4 * k4] = t.x; v[4 * k4 + 1] = t.y; v[4 * k4 + 2] = t.z; v[4 * k4 + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < LNV; ++k) {
+            const int c = lane + 64 * k;
+            v[k] = c < d ? p[c] : 0.f;
+        }
+    }
+}
+template <int LNV, bool VEC4>
+__device__ __forceinline__ void ln_store(float* __restrict__ p, int d, int lane, const float* v) {
+    if (VEC4) {
+#pragma unroll
+        for (int k4 = 0; k4 < LNV / 4; ++k4) {
+            const int c = 4 * lane + 256 * k4;
+            if (c < d) *reinterpret_cast<float4*>(p + c) = make_float4(v[4 * k4], v[4 * k4 + 1], v[4 * k4 + 2], v[4 * k4 + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < LNV; ++k) {
+            const int c = lane + 64 * k;
+            if (c < d) p[c] = v[k];
+        }
+    }
+}
+
+template <int LNV, bool VEC4>
 __global__ void __launch_bounds__(256)
 layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ gamma,
                      const float* __restrict__ beta, long long n_rows, int d, float eps, float* __restrict__ y,
@@ -156,39 +195,35 @@ layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r, c
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + wave;
     if (row >= n_rows) return;
-    const float* xr = x + row * d;
-    const float* rr = r ? r + row * d : nullptr;
-    float v[LNV];
+    float v[LNV], t[LNV];
+    ln_load<LNV, VEC4>(x + row * d, d, lane, v);
+    if (r) {
+        ln_load<LNV, VEC4>(r + row * d, d, lane, t);
+#pragma unroll
+        for (int k = 0; k < LNV; ++k) v[k] += t[k];
+    }
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < LNV; ++k) {
-        const int c = lane + 64 * k;
-        v[k] = 0.f;
-        if (c < d) {
-            v[k] = xr[c] + (rr ? rr[c] : 0.f);
-            s += v[k];
-        }
-    }
+    for (int k = 0; k < LNV; ++k) s += v[k];                     // (columns past d hold zeros)
     const float mean = wave_sum(s) / (float)d;
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < LNV; ++k) {
-        const int c = lane + 64 * k;
-        if (c < d) { const float t = v[k] - mean; q += t * t; }
+        if (ln_col<LNV, VEC4>(lane, k) < d) { const float u = v[k] - mean; q += u * u; }
     }
     const float rstd = 1.f / sqrtf(wave_sum(q) / (float)d + eps);
+    float g[LNV], b[LNV];
+    ln_load<LNV, VEC4>(gamma, d, lane, g);
+    ln_load<LNV, VEC4>(beta, d, lane, b);
 #pragma unroll
-    for (int k = 0; k < LNV; ++k) {
-        const int c = lane + 64 * k;
-        if (c < d) y[row * d + c] = (v[k] - mean) * rstd * gamma[c] + beta[c];
-    }
+    for (int k = 0; k < LNV; ++k) t[k] = (v[k] - mean) * rstd * g[k] + b[k];
+    ln_store<LNV, VEC4>(y + row * d, d, lane, t);
     if (lane == 0) { mean_rstd[2 * row] = mean; mean_rstd[2 * row + 1] = rstd; }
 }
 
-// dz (gradient w.r.t. z = x + r) from dy; xhat recomputed from y: xhat = (y - beta) / gamma is unsafe when
-// gamma ~ 0, so z is re-read instead (z = x + r).  Also accumulates dgamma/dbeta partials with float atomics
-// after a per-workgroup LDS reduction over its 4 rows... kept simple: partials go through colreduce-like LDS.
-template <int LNV>
+// dz (gradient w.r.t. z = x + r) from dy; xhat recomputed from z (re-read: z = x + r).  dgamma / dbeta partials of a
+// workgroup's rows are kept in registers, combined over its four waves through LDS and added with float atomics.
+template <int LNV, bool VEC4>
 __global__ void __launch_bounds__(256)
 layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ dy,
                      const float* __restrict__ gamma, const float* __restrict__ mean_rstd, long long n_rows, int d,
@@ -196,43 +231,46 @@ layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ r, c
                      float* __restrict__ dbeta) {
     extern __shared__ float lds[];          // [2][4][d]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float pg[LNV], pb[LNV];
+    float pg[LNV], pb[LNV], gm[LNV];
 #pragma unroll
     for (int k = 0; k < LNV; ++k) pg[k] = pb[k] = 0.f;
+    ln_load<LNV, VEC4>(gamma, d, lane, gm);
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = min(n_rows, r0 + rows_per_block);
     for (long long row = r0 + wave; row < r1; row += 4) {
         const float mean = mean_rstd[2 * row], rstd = mean_rstd[2 * row + 1];
-        float g[LNV], xh[LNV];
+        float z[LNV], t[LNV], dyv[LNV];
+        ln_load<LNV, VEC4>(x + row * d, d, lane, z);
+        if (r) {
+            ln_load<LNV, VEC4>(r + row * d, d, lane, t);
+#pragma unroll
+            for (int k = 0; k < LNV; ++k) z[k] += t[k];
+        }
+        ln_load<LNV, VEC4>(dy + row * d, d, lane, dyv);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < LNV; ++k) {
-            const int c = lane + 64 * k;
-            g[k] = xh[k] = 0.f;
-            if (c < d) {
-                const float z = x[row * d + c] + (r ? r[row * d + c] : 0.f);
-                const float dyv = dy[row * d + c];
-                xh[k] = (z - mean) * rstd;
-                g[k] = dyv * gamma[c];
-                s1 += g[k];
-                s2 += g[k] * xh[k];
-                pg[k] += dyv * xh[k];
-                pb[k] += dyv;
-            }
+            const bool ok = ln_col<LNV, VEC4>(lane, k) < d;
+            const float xh = ok ? (z[k] - mean) * rstd : 0.f;
+            const float g = dyv[k] * gm[k];                     // (zero past d: dy and gamma load as zeros there)
+            z[k] = xh;
+            t[k] = g;
+            s1 += g;
+            s2 += g * xh;
+            pg[k] += dyv[k] * xh;
+            pb[k] += dyv[k];
         }
         s1 = wave_sum(s1) / (float)d;
         s2 = wave_sum(s2) / (float)d;
 #pragma unroll
-        for (int k = 0; k < LNV; ++k) {
-            const int c = lane + 64 * k;
-            if (c < d) dz[row * d + c] = rstd * (g[k] - s1 - xh[k] * s2);
-        }
+        for (int k = 0; k < LNV; ++k) t[k] = rstd * (t[k] - s1 - z[k] * s2);
+        ln_store<LNV, VEC4>(dz + row * d, d, lane, t);
     }
     float* lg = lds;
     float* lb = lds + 4 * d;
 #pragma unroll
     for (int k = 0; k < LNV; ++k) {
-        const int c = lane + 64 * k;
+        const int c = ln_col<LNV, VEC4>(lane, k);
         if (c < d) { lg[wave * d + c] = pg[k]; lb[wave * d + c] = pb[k]; }
     }
     __syncthreads();
@@ -435,8 +473,12 @@ extern "C" int jova_layernorm_fwd(const float* x, const float* residual, const f
     JOVA_CHECK_ARG(x && gamma && beta && y && mean_rstd && n_rows >= 0, "layernorm_fwd: bad argument");
     JOVA_CHECK_ARG(d >= 1 && d <= 64 * LN_MAXV, "layernorm_fwd: d %d not in [1,%d]", d, 64 * LN_MAXV);
     if (n_rows == 0) return JOVA_OK;
-#define LN_FWD(V) hipLaunchKernelGGL(layernorm_fwd_kernel<V>, dim3(cdiv(n_rows, 4)), dim3(256), 0, (hipStream_t)stream, \
-                                    x, residual, gamma, beta, (long long)n_rows, d, eps, y, mean_rstd)
+    const bool v4 = (d & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)residual) | ((uintptr_t)gamma) | ((uintptr_t)beta) |
+                                      ((uintptr_t)y)) & 15) == 0;
+#define LN_FWD(V) do { if (v4) hipLaunchKernelGGL((layernorm_fwd_kernel<V, true>), dim3(cdiv(n_rows, 4)), dim3(256), 0,  \
+                                    (hipStream_t)stream, x, residual, gamma, beta, (long long)n_rows, d, eps, y, mean_rstd); \
+                       else hipLaunchKernelGGL((layernorm_fwd_kernel<V, false>), dim3(cdiv(n_rows, 4)), dim3(256), 0,     \
+                                    (hipStream_t)stream, x, residual, gamma, beta, (long long)n_rows, d, eps, y, mean_rstd); } while (0)
     if (d <= 256) LN_FWD(4); else if (d <= 512) LN_FWD(8); else if (d <= 1024) LN_FWD(16); else LN_FWD(32);
     JOVA_CHECK_LAUNCH("layernorm_fwd");
     return JOVA_OK;
@@ -451,8 +493,12 @@ extern "C" int jova_layernorm_bwd(const float* x, const float* residual, const f
     int rpb = (int)((n_rows + 1023) / 1024);
     if (rpb < 4) rpb = 4;
     const size_t lds = sizeof(float) * 8 * d;
-#define LN_BWD(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(cdiv(n_rows, rpb)), dim3(256), lds, (hipStream_t)stream, \
-                                    x, residual, dy, gamma, mean_rstd, (long long)n_rows, d, rpb, dz, dgamma, dbeta)
+    const bool v4 = (d & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)residual) | ((uintptr_t)gamma) | ((uintptr_t)dy) |
+                                      ((uintptr_t)dz)) & 15) == 0;
+#define LN_BWD(V) do { if (v4) hipLaunchKernelGGL((layernorm_bwd_kernel<V, true>), dim3(cdiv(n_rows, rpb)), dim3(256), lds, \
+                          (hipStream_t)stream, x, residual, dy, gamma, mean_rstd, (long long)n_rows, d, rpb, dz, dgamma, dbeta); \
+                       else hipLaunchKernelGGL((layernorm_bwd_kernel<V, false>), dim3(cdiv(n_rows, rpb)), dim3(256), lds,   \
+                          (hipStream_t)stream, x, residual, dy, gamma, mean_rstd, (long long)n_rows, d, rpb, dz, dgamma, dbeta); } while (0)
     if (d <= 256) LN_BWD(4); else if (d <= 512) LN_BWD(8); else if (d <= 1024) LN_BWD(16); else LN_BWD(32);
     JOVA_CHECK_LAUNCH("layernorm_bwd");
     return JOVA_OK;
