@@ -132,7 +132,10 @@ int jova_layernorm_bwd(const float* x, const float* residual_or_null, const floa
 
 /* ---- softmax / dropout of nn.MultiheadAttention (jova/nn/models.py:952) and nn.Dropout ------------------------ */
 int jova_softmax_fwd(const float* x, int64_t n_rows, int n, int64_t ld, float* y, void* stream);
-int jova_softmax_bwd(const float* p, const float* dp, int64_t n_rows, int n, int64_t ld, float* ds, void* stream);
+/* p_dropped (optional) = dropout(p) as the forward made it (MHA's attention dropout sits between softmax and P V):
+ * dp is then masked where p_dropped == 0 and scaled by keep_scale = 1 / (1 - prob) inside this kernel. */
+int jova_softmax_bwd(const float* p, const float* dp, const float* p_dropped_or_null, float keep_scale, int64_t n_rows,
+                     int n, int64_t ld, float* ds, void* stream);
 /* y = x * keep / (1-p); keep is a pure function of (seed, offset, element index): call again on dy for backward */
 int jova_dropout(const float* x, int64_t n_rows, int n, int64_t ld, float p, uint64_t seed, uint64_t offset, float* y,
                  void* stream);

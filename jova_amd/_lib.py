@@ -32,7 +32,7 @@ _SIGS = {
     "jova_layernorm_fwd": "pppp" + "qif" + "ppp",
     "jova_layernorm_bwd": "ppppp" + "qi" + "pppp",
     "jova_softmax_fwd": "pqiqpp",
-    "jova_softmax_bwd": "ppqiqpp",
+    "jova_softmax_bwd": "pppfqiqpp",
     "jova_dropout": "pqiqfQQpp",
     "jova_prot2vec_fwd": "pppp" + "iiiiii" + "ppp",
     "jova_prot2vec_bwd": "ppppp" + "iiiiii" + "pp",

@@ -313,11 +313,12 @@ softmax_fwd_kernel(const float* __restrict__ x, long long n_rows, int n, long lo
     }
 }
 
-// ds = p * (dp - sum(dp * p)), in place capable (ds may alias dp)
+// ds = p * (dp' - sum(dp' * p)), dp' = dp (or dp masked and scaled by the dropout that followed the softmax);
+// in place capable (ds may alias dp)
 template <int SMV>
 __global__ void __launch_bounds__(256)
-softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp, long long n_rows, int n, long long ld,
-                   float* __restrict__ ds) {
+softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp, const float* __restrict__ pdrop,
+                   float keep_scale, long long n_rows, int n, long long ld, float* __restrict__ ds) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + wave;
     if (row >= n_rows) return;
@@ -327,7 +328,14 @@ softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp, lo
     for (int k = 0; k < SMV; ++k) {
         const int c = lane + 64 * k;
         pv[k] = dv[k] = 0.f;
-        if (c < n) { pv[k] = p[row * ld + c]; dv[k] = dp[row * ld + c]; s += pv[k] * dv[k]; }
+        if (c < n) {
+            pv[k] = p[row * ld + c];
+            dv[k] = dp[row * ld + c];
+            // dropout between softmax and its consumer: pdrop = dropout(p) as the forward produced it; an element
+            // was kept iff pdrop != 0 (p == 0 elements contribute nothing either way)
+            if (pdrop) dv[k] = pdrop[row * ld + c] != 0.f ? dv[k] * keep_scale : 0.f;
+            s += pv[k] * dv[k];
+        }
     }
     s = wave_sum(s);
 #pragma unroll
@@ -518,17 +526,17 @@ extern "C" int jova_softmax_fwd(const float* x, int64_t n_rows, int n, int64_t l
     return JOVA_OK;
 }
 
-extern "C" int jova_softmax_bwd(const float* p, const float* dp, int64_t n_rows, int n, int64_t ld, float* ds,
-                                void* stream) {
+extern "C" int jova_softmax_bwd(const float* p, const float* dp, const float* p_dropped_or_null, float keep_scale,
+                                int64_t n_rows, int n, int64_t ld, float* ds, void* stream) {
     JOVA_CHECK_ARG(p && dp && ds && n_rows >= 0 && ld >= n, "softmax_bwd: bad argument");
     JOVA_CHECK_ARG(n >= 1 && n <= 64 * SM_MAXV, "softmax_bwd: row length %d not in [1,%d]", n, 64 * SM_MAXV);
     if (n_rows == 0) return JOVA_OK;
     if (n <= 512)
         hipLaunchKernelGGL(softmax_bwd_kernel<8>, dim3(cdiv(n_rows, 4)), dim3(256), 0, (hipStream_t)stream, p, dp,
-                           (long long)n_rows, n, (long long)ld, ds);
+                           p_dropped_or_null, keep_scale, (long long)n_rows, n, (long long)ld, ds);
     else
         hipLaunchKernelGGL(softmax_bwd_kernel<16>, dim3(cdiv(n_rows, 4)), dim3(256), 0, (hipStream_t)stream, p, dp,
-                           (long long)n_rows, n, (long long)ld, ds);
+                           p_dropped_or_null, keep_scale, (long long)n_rows, n, (long long)ld, ds);
     JOVA_CHECK_LAUNCH("softmax_bwd");
     return JOVA_OK;
 }

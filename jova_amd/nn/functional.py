@@ -557,7 +557,6 @@ class JointAttentionFunction(torch.autograd.Function):
             # o[s][b][h*hd + d] = sum_s' pd[b,h][s][s'] v[s'][b][h*hd + d]
             gemm(_addr(pd), Sp, 1, _addr(qkv, 2 * L), bsz * 3 * L, 1, _addr(o), bsz * L, S, hd, S, nb1=bsz, nb2=H,
                  sA=(H * S * Sp, S * Sp), sB=(3 * L, hd), sC=(L, hd))
-            del pd
             xp = _empty((T, L), ref)
             linear_fwd(o, w_o, b_o, xp)
             x1 = _empty((T, L), ref)
@@ -570,7 +569,7 @@ class JointAttentionFunction(torch.autograd.Function):
             x2 = _empty((T, L), ref)
             mr2 = _empty((T, 2), ref)
             call("jova_layernorm_fwd", P(f), P(x1), P(g2), P(be2), T, L, 1e-5, P(x2), P(mr2), stream())
-            saved.append((x, qkv, probs, o, xp, x1, mr1, hid, f, mr2, key))
+            saved.append((x, qkv, probs, o, xp, x1, mr1, hid, f, mr2, pd if p_drop > 0 else None))
             x = x2
         seg_off_dev = torch.tensor(seg_off, dtype=torch.int32).to(ref.device, non_blocking=True)
         out = _empty((bsz, n_views * L), ref)
@@ -595,7 +594,7 @@ class JointAttentionFunction(torch.autograd.Function):
         for i in reversed(range(num_layers)):
             base = 2 * n_views + 2 + 10 * i
             w_in, b_in, w_o, b_o, w1, b1, w2, b2, g2, be2 = params[base: base + 10]
-            x, qkv, probs, o, xp, x1, mr1, hid, f, mr2, key = saved[i]
+            x, qkv, probs, o, xp, x1, mr1, hid, f, mr2, pd_saved = saved[i]
             inner = w1.shape[0]
             # LN2: z2 = f + x1
             dz2 = _empty((T, L), ref)
@@ -618,21 +617,20 @@ class JointAttentionFunction(torch.autograd.Function):
             do = _empty((T, L), ref)
             linear_bwd_data(dz1, w_o, do)
             # attention core
-            pd = probs
-            if p_drop > 0:
-                pd = torch.empty_like(probs)
-                dropout_apply(P(probs), bsz * H * S, S, Sp, p_drop, key[0], key[1], P(pd))
+            # (the dropped probabilities are kept from the forward: 80 MB at Davis size, two passes less than
+            # regenerating the mask twice)
+            pd = pd_saved if p_drop > 0 else probs
             dqkv = _empty((T, 3 * L), ref)
             # dv[s'][d] = sum_s pd[s][s'] do[s][d]
             gemm(_addr(pd), 1, Sp, _addr(do), bsz * L, 1, _addr(dqkv, 2 * L), bsz * 3 * L, S, hd, S, nb1=bsz, nb2=H,
                  sA=(H * S * Sp, S * Sp), sB=(L, hd), sC=(3 * L, hd))
             # dp[s][s'] = sum_d do[s][d] v[s'][d]
-            dp = pd if p_drop > 0 else torch.empty_like(probs)
+            dp = torch.empty_like(probs)
             gemm(_addr(do), bsz * L, 1, _addr(qkv, 2 * L), 1, bsz * 3 * L, _addr(dp), Sp, S, S, hd, nb1=bsz, nb2=H,
                  sA=(L, hd), sB=(3 * L, hd), sC=(H * S * Sp, S * Sp))
-            if p_drop > 0:
-                dropout_apply(P(dp), bsz * H * S, S, Sp, p_drop, key[0], key[1], P(dp))
-            call("jova_softmax_bwd", P(probs), P(dp), bsz * H * S, S, Sp, P(dp), stream())
+            # dropout backward (mask from pd, scale 1 / (1 - p)) rides in the softmax backward
+            call("jova_softmax_bwd", P(probs), P(dp), P(pd) if p_drop > 0 else None, 1.0 / (1.0 - p_drop), bsz * H * S, S,
+                 Sp, P(dp), stream())
             # dq[s][d] = scale * sum_s' ds[s][s'] k[s'][d] ;  dk[s'][d] = scale * sum_s ds[s][s'] q[s][d]
             gemm(_addr(dp), Sp, 1, _addr(qkv, L), bsz * 3 * L, 1, _addr(dqkv), bsz * 3 * L, S, hd, S, alpha=scale,
                  nb1=bsz, nb2=H, sA=(H * S * Sp, S * Sp), sB=(3 * L, hd), sC=(3 * L, hd))

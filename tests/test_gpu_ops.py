@@ -311,6 +311,53 @@ def test_attention_dropout_is_consistent_between_forward_and_backward(device):
     H.assert_close(xg.grad, (y1 != 0).float() / 0.7, tol=1e-6)
 
 
+def test_softmax_backward_with_fused_dropout_mask(device):
+    """jova_softmax_bwd with the dropped probabilities handed in == dropout backward followed by softmax backward."""
+    from jova_amd.nn import functional as F_
+    torch.manual_seed(5)
+    rows, n, ld = 37, 279, 280
+    logits = torch.randn(rows, ld, device=device)
+    probs = torch.zeros(rows, ld, device=device)
+    F_.call("jova_softmax_fwd", F_.P(logits), rows, n, ld, F_.P(probs), F_.stream())
+    pd = torch.zeros_like(probs)
+    F_.dropout_apply(F_.P(probs), rows, n, ld, 0.3, 1234, 7, F_.P(pd))
+    dp = torch.randn(rows, ld, device=device)
+    ds = torch.zeros_like(dp)
+    F_.call("jova_softmax_bwd", F_.P(probs), F_.P(dp), F_.P(pd), 1.0 / 0.7, rows, n, ld, F_.P(ds), F_.stream())
+    p64, d64 = probs[:, :n].double(), dp[:, :n].double()
+    dpm = torch.where(pd[:, :n] != 0, d64 / 0.7, torch.zeros_like(d64))
+    ref = p64 * (dpm - (p64 * dpm).sum(1, keepdim=True))
+    H.assert_close(ds[:, :n], ref.float(), tol=2e-6, what="ds")
+    keep = float((pd[:, :n] != 0).float().mean())
+    assert abs(keep - 0.7) < 0.03
+
+
+def test_joint_attention_gradient_with_attention_dropout(device):
+    """dprob > 0: the forward keeps the dropped attention probabilities and the backward reuses them (no mask replay).
+    Directional finite difference with the masks replayed (same Philox offsets) against the analytic gradient."""
+    from jova_amd.nn import functional as F_
+    from jova_amd.nn.models import JointAttention
+    torch.manual_seed(3)
+    ja = JointAttention(d_dims=[10, 6], latent_dim=16, num_heads=2, num_layers=1, dprob=0.25, inner_layer_dim=32).to(device)
+    ja.train()
+    xs = [torch.randn(5, 8, 10, device=device), torch.randn(7, 8, 6, device=device)]
+    g = torch.randn(8, 32, device=device)
+
+    def loss_of(inputs):
+        F_._DropoutState.offset = 1000
+        return float((ja(inputs) * g).double().sum())
+
+    xg = [x.clone().requires_grad_(True) for x in xs]
+    F_._DropoutState.offset = 1000
+    (ja(xg) * g).sum().backward()
+    dirs = [torch.randn_like(x) for x in xs]
+    analytic = sum(float((x.grad.double() * d.double()).sum()) for x, d in zip(xg, dirs))
+    eps = 2e-3
+    with torch.no_grad():
+        fd = (loss_of([x + eps * d for x, d in zip(xs, dirs)]) - loss_of([x - eps * d for x, d in zip(xs, dirs)])) / (2 * eps)
+    assert abs(fd - analytic) <= 3e-2 * max(abs(analytic), 1.0), (fd, analytic)
+
+
 # ------------------------------------------------------------------------------------------------ end to end
 def _e2e_setup(device):
     from jova_amd.data.collate import DtiBatch, process_gconv_view_data
