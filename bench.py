@@ -247,13 +247,22 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("JOVA_BENCH_WATCHDOG"):              # a stuck run dumps every thread's stack and exits
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["JOVA_BENCH_WATCHDOG"]), exit=True)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev:
+        raise SystemExit("rank %d has no GPU of its own (%d visible): one process per GPU" % (local_rank, n_dev))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # JOVA_BENCH_FORCE_DIST=1 (under torch.distributed.run --nproc-per-node 1): the N-rank flow -- RCCL group, overlapped
+    # gradient all-reduce, barriers, max over ranks -- on a one-rank group; a rehearsal for one-GPU boxes
+    dist_on = world > 1 or bool(os.environ.get("JOVA_BENCH_FORCE_DIST"))
     pg = None
-    if world > 1:
+    if dist_on:
         torch.distributed.init_process_group("nccl", device_id=device)
         pg = torch.distributed.group.WORLD
 
@@ -265,13 +274,13 @@ def main():
     torch.manual_seed(1)                                   # identical initial weights on every rank
     model = create_integrated_net(hp, pool.protein_profile).to(device).train()
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    trainer = Trainer(model, hp, world_size=world, process_group=pg)
+    trainer = Trainer(model, hp, world_size=world, process_group=pg, force_sync=dist_on)
     prot2vec = model[0].models[2][0]
     batches = build_batches(pool, conv_mols, hp, device, 8, seed=1000 + rank, prot2vec=prot2vec)
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -285,7 +294,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     probe = F_.PROBE.pop("ffn1_fwd")
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -313,6 +322,8 @@ def main():
                             global_batch=bsz * world, parallelism="dp%d" % world,
                             trainable_params=count_parameters(model)),
                 final_loss=round(final_loss, 6), roofline=roofline)
+    if dist_on and world == 1:
+        line["rehearsal"] = "N-rank flow on a one-rank RCCL group"
     if rank == 0 and world == 1:
         if not args.no_graph_stress:
             line["graph_roofline"] = graph_stress(device)
@@ -322,7 +333,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(pool, hp, pool.sample_pairs(r, bsz), sd0, args.cpu_steps, threads)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

@@ -573,8 +573,13 @@ extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
     const bool vb = aligned16(B) && (b_ld % 4 == 0) && (sB1 % 4 == 0) && (sB2 % 4 == 0) && ((b_kc ? K : N) % 4 == 0);
     g.vecA = va; g.vecB = vb;
     hipStream_t s = (hipStream_t)stream;
-    static int fast_env = -1;
+    static int fast_env = -1, trace_env = -1;
     if (fast_env < 0) fast_env = getenv("JOVA_GEMM_NO_FAST") ? 0 : 1;
+    if (trace_env < 0) trace_env = getenv("JOVA_GEMM_TRACE") ? 1 : 0;                // one line per call on stderr
+    if (trace_env)
+        fprintf(stderr, "gemm M=%d N=%d K=%d a_kc=%d b_kc=%d va=%d vb=%d nb=%dx%d splitk=%d relu=%d res=%d lda=%lld ldb=%lld ldc=%lld\n",
+                M, N, K, (int)a_kc, (int)b_kc, (int)va, (int)vb, nb1, nb2, splitk, relu, residual != nullptr,
+                (long long)a_ld, (long long)b_ld, (long long)ldc);
     const bool fast = fast_env && nb1 == 1 && nb2 == 1 && M % 128 == 0 && N % 128 == 0 && K % FBK == 0 && K > 0 && va &&
                       vb && aligned16(C) && (!residual || true);
     if (fast) {

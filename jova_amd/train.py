@@ -12,6 +12,8 @@ Differences that are deliberate (MI355X-first):
     kernel over the flat buffers;
   * batches are collated to device-resident index tensors (jova_amd/data/collate.py) instead of per-step Python.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -172,7 +174,7 @@ def encoder_param_split(model, flat):
 class Trainer(object):
     """One training step = the body of the reference's batch loop (train_joint_attn.py:428-486), no host sync."""
 
-    def __init__(self, model, hparams, world_size=1, process_group=None):
+    def __init__(self, model, hparams, world_size=1, process_group=None, force_sync=False):
         self.model = model
         self.hp = hparams
         self.flat = FlatParameters(model)
@@ -183,7 +185,9 @@ class Trainer(object):
         self.wd = float(hparams.get("optimizer__global__weight_decay", 0.0))
         self.step_idx = 0
         self.sync = None
-        if world_size > 1:
+        # (force_sync: run the collectives of the N-rank step on a one-rank group -- rehearsal on a one-GPU box)
+        self.collective = world_size > 1 or force_sync
+        if self.collective and not os.environ.get("JOVA_NO_OVERLAP"):   # knob: one all-reduce after backward
             split = encoder_param_split(model, self.flat)
             if split is not None:
                 self.sync = OverlappedGradSync(self.flat, split, process_group)
@@ -209,7 +213,7 @@ class Trainer(object):
         loss, outputs = self.forward_loss(batch)
         loss.backward()
         scale = 1.0
-        if self.world_size > 1:
+        if self.collective:
             if self.sync is not None:
                 self.sync.finish()                                            # RCCL sums; mean via scale
             else:
