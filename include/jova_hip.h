@@ -34,7 +34,9 @@ int jova_abi_version(void);
  * out [N, f_out] = act( W_rel[d] . sum_nbr x + b_rel[d] + W_self[d] . x + b_self[d] ).
  * bn_stats (optional, fp64 [2, f_out]): column sum / sum of squares of `out` for the BatchNorm1d that follows.
  * packed_ws: scratch of jova_graphconv_workspace_floats(f_in, f_out) floats.
- * deg_slice_host: optional HOST copy of deg_slice (see jova_graphconv_bwd). */
+ * deg_slice_host: optional HOST copy of deg_slice (see jova_graphconv_bwd).
+ * N == 0 (an empty batch) is legal in every graph entry point: nothing is launched and the per-atom pointers may be
+ * null. */
 int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t ld_atoms, int64_t n_atoms, int f_in, int f_out,
                        const int64_t* deg_slice, const int32_t* const* adj, const float* const* weight,
                        const float* const* bias, int relu, float* out, double* bn_stats, float* packed_ws,

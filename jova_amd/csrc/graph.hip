@@ -1855,7 +1855,8 @@ extern "C" int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t l
     JOVA_CHECK_ARG(f_in >= 1 && f_in <= 128, "graphconv_fwd: f_in %d not in [1,128]", f_in);
     JOVA_CHECK_ARG(f_out >= 1, "graphconv_fwd: f_out %d", f_out);
     JOVA_CHECK_ARG(ld_atoms >= f_in && ld_atoms < (1 << 20), "graphconv_fwd: ld_atoms %lld < f_in", (long long)ld_atoms);
-    JOVA_CHECK_ARG(atoms && deg_slice && adj && weight && bias && out && packed_ws, "graphconv_fwd: null pointer");
+    // (an empty batch has no per-atom buffers: those pointers may be null when n_atoms == 0)
+    JOVA_CHECK_ARG(deg_slice && adj && weight && bias && packed_ws && (n_atoms == 0 || (atoms && out)), "graphconv_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     if (bn_stats) JOVA_CHECK_HIP(hipMemsetAsync(bn_stats, 0, sizeof(double) * 2 * f_out, s));
     if (n_atoms == 0) return JOVA_OK;
@@ -1935,7 +1936,7 @@ extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t l
     JOVA_CHECK_ARG(f_in >= 1 && f_in <= 128, "graphconv_bwd: f_in %d not in [1,128]", f_in);
     JOVA_CHECK_ARG(f_out >= 1 && f_out <= 64, "graphconv_bwd: f_out %d not in [1,64]", f_out);
     JOVA_CHECK_ARG(ld_atoms >= f_in && ld_atoms < (1 << 20), "graphconv_bwd: ld_atoms %lld < f_in", (long long)ld_atoms);
-    JOVA_CHECK_ARG(atoms && deg_slice && adj && dy && dweight && dbias, "graphconv_bwd: null pointer");
+    JOVA_CHECK_ARG(deg_slice && adj && dweight && dbias && (n_atoms == 0 || (atoms && dy)), "graphconv_bwd: null pointer");
     JOVA_CHECK_ARG(!dx_or_null || (gbuf_or_null && weight && !atoms_is_i64), "graphconv_bwd: dx needs gbuf, weights, f32 atoms");
     if (n_atoms == 0) return JOVA_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -2050,7 +2051,7 @@ extern "C" int jova_adj_reverse_pos(int64_t n_atoms, const int64_t* deg_slice, c
 
 extern "C" int jova_graphpool_fwd(const float* x, int64_t n_atoms, int f, const int64_t* deg_slice,
                                   const int32_t* const* adj, float* out, uint8_t* argmax, void* stream) {
-    JOVA_CHECK_ARG(x && deg_slice && adj && out && argmax, "graphpool_fwd: null pointer");
+    JOVA_CHECK_ARG(deg_slice && adj && (n_atoms == 0 || (x && out && argmax)), "graphpool_fwd: null pointer");
     JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 31) && f >= 1, "graphpool_fwd: bad shape");
     if (n_atoms == 0) return JOVA_OK;
     GcParams P;
@@ -2068,7 +2069,7 @@ extern "C" int jova_graphpool_fwd(const float* x, int64_t n_atoms, int f, const 
 extern "C" int jova_graphpool_bwd(const float* dy, const uint8_t* argmax, int64_t n_atoms, int f,
                                   const int64_t* deg_slice, const int32_t* const* adj, float* dx, const int* sym_flag,
                                   int sym_flag_host_hint, const uint8_t* rev_pos_or_null, void* stream) {
-    JOVA_CHECK_ARG(dy && argmax && deg_slice && adj && dx, "graphpool_bwd: null pointer");
+    JOVA_CHECK_ARG(deg_slice && adj && (n_atoms == 0 || (dy && argmax && dx)), "graphpool_bwd: null pointer");
     JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 31) && f >= 1, "graphpool_bwd: bad shape");
     if (n_atoms == 0) return JOVA_OK;
     hipStream_t s = (hipStream_t)stream;

@@ -358,6 +358,74 @@ def test_joint_attention_gradient_with_attention_dropout(device):
     assert abs(fd - analytic) <= 3e-2 * max(abs(analytic), 1.0), (fd, analytic)
 
 
+@pytest.mark.parametrize("opt", ["sgd", "sgd_momentum", "adamax"])
+def test_optimizer_step_vs_torch_optim(device, opt):
+    """jova_sgd_step / jova_adamax_step against torch.optim on the host (the reference builds its optimizer from
+    torch.optim: proj/dti/train_joint_attn.py:485-486 steps it), four steps with weight decay on a flat buffer whose
+    length is not a multiple of the vector width; grad_scale = 1/2 stands for the mean over two ranks."""
+    from jova_amd.nn import functional as F_
+    torch.manual_seed(11)
+    n, lr, wd = 100003, 0.05, 0.01
+    p0 = torch.randn(n)
+    grads = [torch.randn(n) * (0.5 + k) for k in range(4)]
+    ref = torch.nn.Parameter(p0.clone())
+    if opt == "adamax":
+        o = torch.optim.Adamax([ref], lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    else:
+        o = torch.optim.SGD([ref], lr=lr, weight_decay=wd, momentum=0.9 if opt == "sgd_momentum" else 0.0)
+    p = p0.clone().to(device)
+    m1, m2 = torch.zeros(n, device=device), torch.zeros(n, device=device)
+    for k, g in enumerate(grads):
+        ref.grad = g.clone()
+        o.step()
+        g2 = (2.0 * g).to(device)                       # the sum over two ranks; the kernel scales by 1/2
+        if opt == "adamax":
+            F_.call("jova_adamax_step", F_.P(p), F_.P(g2), F_.P(m1), F_.P(m2), n, lr, 0.9, 0.999, 1e-8, wd, 0.5, k + 1,
+                    F_.stream())
+        else:
+            mom = 0.9 if opt == "sgd_momentum" else 0.0
+            F_.call("jova_sgd_step", F_.P(p), F_.P(g2), F_.P(m1) if mom else None, n, lr, wd, mom, 0.5, int(k == 0),
+                    F_.stream())
+    H.assert_close(p, ref.detach(), tol=2e-6, what="params after 4 %s steps" % opt)
+
+
+def test_graph_kernels_on_empty_and_single_atom_batches(device):
+    """Edge cases of the batch graph through the C ABI: no atoms at all (every launch is skipped, status OK), and one
+    molecule of one atom (degree 0 only: the self weights of bucket 0, no neighbour term; pooling is the identity)."""
+    from jova_amd.nn import functional as F_
+    from jova_amd.nn.layers import GraphConvLayer, GraphPool
+    torch.manual_seed(2)
+    conv = GraphConvLayer(64, 64, activation=None).to(device)
+    pool = GraphPool()
+
+    def gconv_input(n):
+        ds = torch.zeros(11, 2, dtype=torch.int64)
+        ds[0, 1] = n                                             # all atoms in the degree-0 bucket
+        adj = [torch.zeros(0, d, dtype=torch.int32, device=device) for d in range(1, 11)]
+        return [torch.randn(n, 64, device=device, requires_grad=True), ds.to(device), None, [n] if n else []] + adj
+
+    data = gconv_input(0)
+    y = conv(data)
+    assert tuple(y.shape) == (0, 64)
+    yp = pool([y] + data[1:])
+    assert tuple(yp.shape) == (0, 64)
+    yp.sum().backward()                                          # backward of nothing: zero weight gradients
+    assert all(l.weight.grad is None or float(l.weight.grad.abs().max()) == 0.0 for l in conv.linear_layers)
+    conv.zero_grad()
+    data = gconv_input(1)
+    y = conv(data)
+    lin = conv.linear_layers[20]                                 # the degree-0 self weights (layers.py:330-336)
+    want = data[0].detach() @ lin.weight.detach().t() + lin.bias.detach()
+    H.assert_close(y.detach(), want, tol=1e-5, what="degree-0 atom")
+    yp = pool([y] + data[1:])
+    assert torch.equal(yp.detach(), y.detach())
+    yp.sum().backward()
+    torch.cuda.synchronize()
+    H.assert_close(data[0].grad, lin.weight.detach().sum(0, keepdim=True), tol=1e-5, what="dx of the degree-0 atom")
+    H.assert_close(lin.weight.grad, data[0].detach().expand(64, 64).contiguous(), tol=1e-5, what="dW of bucket 0")
+    assert all(float(l.weight.grad.abs().max()) == 0.0 for l in conv.linear_layers[:20] if l.weight.grad is not None)
+
+
 # ------------------------------------------------------------------------------------------------ end to end
 def _e2e_setup(device):
     from jova_amd.data.collate import DtiBatch, process_gconv_view_data

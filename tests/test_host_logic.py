@@ -98,6 +98,17 @@ def test_abi_argument_errors_are_reported_without_a_gpu():
                   4, 1.0, None, None, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, None)
 
 
+def test_abi_accepts_an_empty_batch_without_a_gpu():
+    """n_atoms == 0: the graph entry points return OK before any HIP call; per-atom pointers may be null."""
+    from jova_amd import _lib
+    tok = ctypes.c_void_p(16)                                    # non-null stand-in for the per-batch tables (never read)
+    _lib.call("jova_graphconv_fwd", None, 0, 64, 0, 64, 64, tok, tok, tok, tok, 1, None, None, tok, None, None)
+    _lib.call("jova_graphpool_fwd", None, 0, 64, tok, tok, None, None, None)
+    _lib.call("jova_graphpool_bwd", None, None, 0, 64, tok, tok, None, None, 0, None, None)
+    with pytest.raises(RuntimeError, match="null pointer"):     # ... but not when there are atoms
+        _lib.call("jova_graphpool_fwd", None, 5, 64, tok, tok, None, None, None)
+
+
 def test_state_dict_matches_reference_manifest():
     """Same keys and shapes as the reference's create_integrated_net at the tuned config => .mod files load as is."""
     from jova_amd.train import TUNED_DAVIS_HPARAMS, count_parameters, create_integrated_net
