@@ -180,8 +180,12 @@ def graph_stress(device, reps=20, full=True):
     timed("graphconv_fwd_l2(64->64)", lambda: call("jova_graphconv_fwd", P(x2), 0, 64, n, 64, 64, ds, adj, pw2, pb2, 1,
                                                    P(out), None, P(ws2), dsh, st),
           4 * (n * 64 + n * 64 + e) + wbytes, launches=2, kernels=("graphconv_fwd_dma_kernel<8, 4>",))
-    timed("graphpool_fwd(64)", lambda: call("jova_graphpool_fwd", P(x2), n, 64, ds, adj, P(out), P(arg), st),
+    order = P(topo.block_order)
+    timed("graphpool_fwd(64)", lambda: call("jova_graphpool_fwd", P(x2), n, 64, ds, adj, P(out), P(arg), order, st),
           4 * (2 * n * 64 + e) + n * 64, kernels=("graphpool_fwd_v4_kernel",))
+    timed("graphpool_fwd(64), blocks in row order",
+          lambda: call("jova_graphpool_fwd", P(x2), n, 64, ds, adj, P(out), P(arg), None, st),
+          4 * (2 * n * 64 + e) + n * 64, kernels=())
     if full:
         # backward kernels accumulate into gradient buffers (as in the trainer).  In the model the BatchNorm behind
         # each convolution applies the backward of the convolution's ReLU (it reads that output anyway), so the
@@ -204,8 +208,12 @@ def graph_stress(device, reps=20, full=True):
               4 * (n * 64 + 3 * n * 64 + e) + 2 * wbytes, launches=2,
               kernels=("graphconv_bwd_dma_kernel<8, true, false, 4, false>", "graphconv_bwd_dx_v4_kernel"))
         timed("graphpool_bwd(64)", lambda: call("jova_graphpool_bwd", P(dz), P(arg), n, 64, ds, adj, P(dx),
-                                                P(topo.sym_flag), sym, P(topo.rev_pos), st),
+                                                P(topo.sym_flag), sym, P(topo.rev_pos), order, st),
               4 * (2 * n * 64 + e) + n * 64, kernels=("graphpool_bwd_v5_kernel",))
+        timed("graphpool_bwd(64), blocks in row order",
+              lambda: call("jova_graphpool_bwd", P(dz), P(arg), n, 64, ds, adj, P(dx), P(topo.sym_flag), sym,
+                           P(topo.rev_pos), None, st),
+              4 * (2 * n * 64 + e) + n * 64, kernels=())
     if full:
         # GraphGather2D (contiguous chunks -> zero-padded [A_max, B, g]) and the nonsat activation on it, g = 128
         g = 128

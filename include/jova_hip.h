@@ -71,12 +71,18 @@ int jova_adj_symmetry(int64_t n_atoms, const int64_t* deg_slice, const int32_t* 
  * argmax uint8 [N, f]: 0 = self, k = k-th neighbour.  Backward: sym_flag = device flag of jova_adj_symmetry;
  * host_knows_symmetric = 1 when the caller has read that flag as 1 (selects the pure-gather kernel, no memset);
  * rev_pos (optional, from jova_adj_reverse_pos, symmetric graphs only) spares that kernel the search of every
- * neighbour's list. */
+ * neighbour's list.
+ * block_order (optional, DEVICE int32 [ceil(N/16)], a permutation of the 16-row block numbers; jova_block_order
+ * makes it on the host once per batch): which block each workgroup takes, arranged so that an atom's row and its
+ * neighbours' reads of it meet in one XCD's L2.  Results do not depend on it; NULL = blocks in row order. */
 int jova_graphpool_fwd(const float* x, int64_t n_atoms, int f, const int64_t* deg_slice, const int32_t* const* adj,
-                       float* out, uint8_t* argmax, void* stream);
+                       float* out, uint8_t* argmax, const int32_t* block_order_or_null, void* stream);
 int jova_graphpool_bwd(const float* dy, const uint8_t* argmax, int64_t n_atoms, int f, const int64_t* deg_slice,
                        const int32_t* const* adj, float* dx, const int* sym_flag, int host_knows_symmetric,
-                       const uint8_t* rev_pos_or_null, void* stream);
+                       const uint8_t* rev_pos_or_null, const int32_t* block_order_or_null, void* stream);
+/* host-only (no GPU call): order_host receives ceil(n_atoms/16) ints from the HOST copy of deg_slice.  No
+ * counterpart in the reference: an MI355X placement hint (8 XCDs, one L2 each). */
+int jova_block_order(const int64_t* deg_slice_host, int64_t n_atoms, int32_t* order_host);
 /* rev_pos uint8 [sum_d n_d * d] (laid out like adj_1 | adj_2 | .. | adj_10): for atom i's n-th neighbour j the 1-based
  * position of i in j's own list, 0xFF if absent.  A property of the batch graph (mol_graphs.py:340-378 builds both
  * directions of every bond); built once per batch. */

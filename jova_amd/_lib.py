@@ -17,8 +17,9 @@ _SIGS = {
     "jova_atoms_to_f32": "pqiipp",
     "jova_graphconv_bwd": "piqqiippp" + "pppp" + "pppppp",
     "jova_adj_symmetry": "qpppp",
-    "jova_graphpool_fwd": "pqipp" + "ppp",
-    "jova_graphpool_bwd": "ppqipp" + "ppipp",
+    "jova_graphpool_fwd": "pqipp" + "pppp",
+    "jova_block_order": "pqp",
+    "jova_graphpool_bwd": "ppqipp" + "ppippp",
     "jova_adj_reverse_pos": "qpppp",
     "jova_gather2d_fwd": "ppiiipp",
     "jova_gather2d_bwd": "ppiiipp",

@@ -10,6 +10,9 @@
 #include "jova_hip.h"
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <utility>
+#include <vector>
 
 #define TM 64
 #define NB 11
@@ -1360,6 +1363,14 @@ graphpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restri
 
 // ---- 16-lanes-per-row forms (f % 4 == 0): a wave works on 4 atoms at once with float4 loads, the first four
 // neighbour rows of each in flight together; used whenever the rows are 16-byte multiples (the model's f = 64).
+// Block order (optional, made once per batch by jova_block_order): blockIdx -> 16-row block.  Workgroup b runs on XCD
+// b % 8; the order hands each XCD the blocks of one eighth of every degree bucket (by relative position), interleaved
+// across buckets, so an atom's row and the reads of it by its neighbours (which sit at about the same relative
+// position of their own buckets) meet in ONE L2 close in time instead of in eight L2s a whole bucket sweep apart.
+__device__ __forceinline__ int ordered_block(const int* __restrict__ order) {
+    return order ? min(max(order[blockIdx.x], 0), (int)gridDim.x - 1) : (int)blockIdx.x;
+}
+
 __device__ __forceinline__ void find_bucket(const long long* __restrict__ deg_slice, long long row, int& deg,
                                             long long& lrow) {
     deg = 0;
@@ -1373,9 +1384,10 @@ __device__ __forceinline__ void find_bucket(const long long* __restrict__ deg_sl
 
 __global__ void __launch_bounds__(256)
 graphpool_fwd_v4_kernel(const float* __restrict__ x, int n_atoms, int f, const long long* __restrict__ deg_slice,
-                        GcParams P, float* __restrict__ out, unsigned char* __restrict__ arg) {
+                        GcParams P, float* __restrict__ out, unsigned char* __restrict__ arg,
+                        const int* __restrict__ order) {
     const int l16 = threadIdx.x & 15;
-    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long long row = (long long)ordered_block(order) * 16 + (threadIdx.x >> 4);
     if (row >= n_atoms) return;
     int deg;
     long long lrow;
@@ -1514,9 +1526,10 @@ adj_reverse_pos_kernel(int n_atoms, const long long* __restrict__ deg_slice, GcP
 __global__ void __launch_bounds__(256)
 graphpool_bwd_v5_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg, int n_atoms, int f,
                         const long long* __restrict__ deg_slice, GcParams P,
-                        const unsigned char* __restrict__ rev_pos, float* __restrict__ dx) {
+                        const unsigned char* __restrict__ rev_pos, float* __restrict__ dx,
+                        const int* __restrict__ order) {
     const int l16 = threadIdx.x & 15;
-    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long long row = (long long)ordered_block(order) * 16 + (threadIdx.x >> 4);
     if (row >= n_atoms) return;
     int deg;
     long long lrow, eoff;
@@ -2049,8 +2062,36 @@ extern "C" int jova_adj_reverse_pos(int64_t n_atoms, const int64_t* deg_slice, c
     return JOVA_OK;
 }
 
+// Host-side: the XCD-aware order of the 16-row blocks (see ordered_block).  order_host receives ceil(n_atoms/16) ints,
+// a permutation of the block numbers.
+extern "C" int jova_block_order(const int64_t* deg_slice_host, int64_t n_atoms, int32_t* order_host) {
+    JOVA_CHECK_ARG(deg_slice_host && order_host && n_atoms >= 0 && n_atoms < (1ll << 31), "block_order: bad argument");
+    const int n = (int)cdiv(n_atoms, 16);
+    if (n == 0) return JOVA_OK;
+    std::vector<std::pair<double, int>> key((size_t)n);
+    for (int t = 0; t < n; ++t) {
+        const long long row0 = 16ll * t;
+        double rel = 0.0;
+        for (int d = 0; d < NB; ++d) {
+            const long long st = deg_slice_host[2 * d], sz = deg_slice_host[2 * d + 1];
+            if (row0 >= st && row0 < st + sz) rel = (double)(row0 - st) / (double)sz;
+        }
+        key[(size_t)t] = std::make_pair(rel, t);
+    }
+    std::stable_sort(key.begin(), key.end());
+    const int q = n / 8, r = n % 8;
+    int off = 0;
+    for (int k = 0; k < 8; ++k) {                                  // XCD k: the k-th eighth of the sorted list
+        const int cnt = q + (k < r ? 1 : 0);
+        for (int loc = 0; loc < cnt; ++loc) order_host[loc * 8 + k] = key[(size_t)(off + loc)].second;
+        off += cnt;
+    }
+    return JOVA_OK;
+}
+
 extern "C" int jova_graphpool_fwd(const float* x, int64_t n_atoms, int f, const int64_t* deg_slice,
-                                  const int32_t* const* adj, float* out, uint8_t* argmax, void* stream) {
+                                  const int32_t* const* adj, float* out, uint8_t* argmax,
+                                  const int32_t* block_order_or_null, void* stream) {
     JOVA_CHECK_ARG(deg_slice && adj && (n_atoms == 0 || (x && out && argmax)), "graphpool_fwd: null pointer");
     JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 31) && f >= 1, "graphpool_fwd: bad shape");
     if (n_atoms == 0) return JOVA_OK;
@@ -2058,7 +2099,7 @@ extern "C" int jova_graphpool_fwd(const float* x, int64_t n_atoms, int f, const 
     fill_params(P, adj, nullptr, nullptr);
     if ((f & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)out) | ((uintptr_t)argmax)) & 15) == 0)
         hipLaunchKernelGGL(graphpool_fwd_v4_kernel, dim3(cdiv(n_atoms, 16)), dim3(256), 0, (hipStream_t)stream, x,
-                           (int)n_atoms, f, (const long long*)deg_slice, P, out, argmax);
+                           (int)n_atoms, f, (const long long*)deg_slice, P, out, argmax, block_order_or_null);
     else
         hipLaunchKernelGGL(graphpool_fwd_kernel, dim3(cdiv(n_atoms, 4)), dim3(256), 0, (hipStream_t)stream, x,
                            (int)n_atoms, f, (const long long*)deg_slice, P, out, argmax);
@@ -2068,7 +2109,8 @@ extern "C" int jova_graphpool_fwd(const float* x, int64_t n_atoms, int f, const 
 
 extern "C" int jova_graphpool_bwd(const float* dy, const uint8_t* argmax, int64_t n_atoms, int f,
                                   const int64_t* deg_slice, const int32_t* const* adj, float* dx, const int* sym_flag,
-                                  int sym_flag_host_hint, const uint8_t* rev_pos_or_null, void* stream) {
+                                  int sym_flag_host_hint, const uint8_t* rev_pos_or_null,
+                                  const int32_t* block_order_or_null, void* stream) {
     JOVA_CHECK_ARG(deg_slice && adj && (n_atoms == 0 || (dy && argmax && dx)), "graphpool_bwd: null pointer");
     JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 31) && f >= 1, "graphpool_bwd: bad shape");
     if (n_atoms == 0) return JOVA_OK;
@@ -2079,7 +2121,8 @@ extern "C" int jova_graphpool_bwd(const float* dy, const uint8_t* argmax, int64_
     if (sym_flag_host_hint == 1 && (f & 3) == 0 && ((((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)argmax)) & 15) == 0) {
         if (rev_pos_or_null) {
             hipLaunchKernelGGL(graphpool_bwd_v5_kernel, dim3(cdiv(n_atoms, 16)), dim3(256), 0, s, dy, argmax,
-                               (int)n_atoms, f, (const long long*)deg_slice, P, rev_pos_or_null, dx);
+                               (int)n_atoms, f, (const long long*)deg_slice, P, rev_pos_or_null, dx,
+                               block_order_or_null);
             JOVA_CHECK_LAUNCH("graphpool_bwd_v5");
             return JOVA_OK;
         }

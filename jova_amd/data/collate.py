@@ -6,6 +6,8 @@ n_atoms_lst, adj_1 .. adj_10]`` and moves each piece to the GPU separately.  Her
 vectorised ConvMol.agglomerate_mols, packed into ONE pinned host buffer and uploaded with a single async copy; the
 per-batch topology (symmetry flag, molecule offsets) is derived once on the device.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -22,7 +24,13 @@ def process_gconv_view_data(mols, device):
     # one packed upload: int64 region (atoms, deg_slice, membership) then int32 region (adjacency, molecule offsets)
     mol_off = np.concatenate([[0], np.cumsum(n_atoms_lst)]).astype(np.int32)
     i64_parts = [mm.nodes.astype(np.int64, copy=False).reshape(-1), mm.deg_slice.reshape(-1), membership]
-    i32_parts = [a.reshape(-1) for a in adj] + [mol_off]
+    ds_host = np.ascontiguousarray(mm.deg_slice, dtype=np.int64).copy()
+    n_blocks = (int(mm.nodes.shape[0]) + 15) // 16
+    order = np.zeros(n_blocks, dtype=np.int32)                   # XCD-aware block order of the gather kernels
+    if device.type == "cuda" and n_blocks:
+        F_.call("jova_block_order", ctypes.c_void_p(ds_host.ctypes.data), int(mm.nodes.shape[0]),
+                ctypes.c_void_p(order.ctypes.data))
+    i32_parts = [a.reshape(-1) for a in adj] + [mol_off, order]
     n64 = sum(p.size for p in i64_parts)
     n32 = sum(p.size for p in i32_parts)
     host = torch.empty(n64 * 8 + n32 * 4, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
@@ -51,7 +59,9 @@ def process_gconv_view_data(mols, device):
     if device.type == "cuda":
         topo = F_.Topology(deg_slice, glist[4:], n_atoms_lst, n)
         topo._mol_off = d32[o:o + len(n_atoms_lst) + 1]
-        topo._deg_slice_host = np.ascontiguousarray(mm.deg_slice, dtype=np.int64).copy()
+        topo._deg_slice_host = ds_host
+        o += len(n_atoms_lst) + 1
+        topo._block_order = d32[o:o + n_blocks]
         deg_slice._jova_topology = topo
     return glist
 

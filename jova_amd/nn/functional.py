@@ -85,6 +85,7 @@ class Topology(object):
         self._sym_host = None
         self._deg_slice_host = None
         self._rev_pos = None
+        self._block_order = None
 
     def atoms_f32(self, atoms):
         """fp32 copy of the batch's int64 atom features, rows zero-padded to a multiple of 16 floats (made once)."""
@@ -106,6 +107,18 @@ class Topology(object):
             self._rev_pos = torch.empty(max(n_edges, 1), dtype=torch.uint8, device=self.deg_slice.device)
             call("jova_adj_reverse_pos", self.n_atoms, P(self.deg_slice), self.adj_ptrs, P(self._rev_pos), stream())
         return self._rev_pos
+
+    @property
+    def block_order(self):
+        """XCD-aware order of the 16-row blocks for the gather kernels (jova_block_order; once per batch; the
+        collator ships it inside its packed upload)."""
+        if self._block_order is None:
+            n = (self.n_atoms + 15) // 16
+            host = np.zeros(max(n, 1), dtype=np.int32)
+            call("jova_block_order", ctypes.c_void_p(self.deg_slice_host.ctypes.data), self.n_atoms,
+                 ctypes.c_void_p(host.ctypes.data))
+            self._block_order = torch.from_numpy(host).to(self.deg_slice.device)
+        return self._block_order
 
     @property
     def deg_slice_host(self):
@@ -202,7 +215,8 @@ class GraphPoolFunction(torch.autograd.Function):
         n, f = atoms.shape
         out = _empty((n, f), atoms)
         arg = _empty((n, f), atoms, torch.uint8)
-        call("jova_graphpool_fwd", P(atoms), n, f, P(topo.deg_slice), topo.adj_ptrs, P(out), P(arg), stream())
+        call("jova_graphpool_fwd", P(atoms), n, f, P(topo.deg_slice), topo.adj_ptrs, P(out), P(arg),
+             P(topo.block_order) if n else None, stream())
         ctx.topo = topo
         ctx.save_for_backward(arg)
         return out
@@ -215,7 +229,7 @@ class GraphPoolFunction(torch.autograd.Function):
         n, f = dy.shape
         dx = _empty((n, f), dy)
         call("jova_graphpool_bwd", P(dy), P(arg), n, f, P(topo.deg_slice), topo.adj_ptrs, P(dx), P(topo.sym_flag),
-             int(topo.symmetric), P(topo.rev_pos), stream())
+             int(topo.symmetric), P(topo.rev_pos), P(topo.block_order) if n else None, stream())
         return dx, None
 
 

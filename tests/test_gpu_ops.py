@@ -757,14 +757,25 @@ def test_config4_graph_stack_vs_oracle(device):
     arg = torch.empty(o2.shape, dtype=torch.uint8, device=device)
     tmp = torch.empty_like(o2)
     F_.call("jova_graphpool_fwd", F_.P(o1), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs, F_.P(tmp), F_.P(arg),
-            F_.stream())
+            None, F_.stream())
+    # the XCD-aware block order is a permutation of the 16-row blocks and changes nothing in the results
+    order = topo.block_order
+    assert torch.equal(torch.sort(order.long()).values.cpu(), torch.arange((o1.shape[0] + 15) // 16))
+    tmp2, arg2 = torch.empty_like(tmp), torch.empty_like(arg)
+    F_.call("jova_graphpool_fwd", F_.P(o1), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs, F_.P(tmp2), F_.P(arg2),
+            F_.P(order), F_.stream())
+    assert torch.equal(tmp, tmp2) and torch.equal(arg, arg2)
     dx_g, dx_s, dx_r = torch.empty_like(o2), torch.empty_like(o2), torch.empty_like(o2)
     F_.call("jova_graphpool_bwd", F_.P(dy), F_.P(arg), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs,
-            F_.P(dx_g), F_.P(topo.sym_flag), 1, None, F_.stream())
+            F_.P(dx_g), F_.P(topo.sym_flag), 1, None, None, F_.stream())
     F_.call("jova_graphpool_bwd", F_.P(dy), F_.P(arg), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs,
-            F_.P(dx_r), F_.P(topo.sym_flag), 1, F_.P(topo.rev_pos), F_.stream())
+            F_.P(dx_r), F_.P(topo.sym_flag), 1, F_.P(topo.rev_pos), None, F_.stream())
+    dx_o = torch.empty_like(o2)
     F_.call("jova_graphpool_bwd", F_.P(dy), F_.P(arg), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs,
-            F_.P(dx_s), None, 0, None, F_.stream())
+            F_.P(dx_o), F_.P(topo.sym_flag), 1, F_.P(topo.rev_pos), F_.P(order), F_.stream())
+    assert torch.equal(dx_o, dx_r), "pool backward: the block order changes the result"
+    F_.call("jova_graphpool_bwd", F_.P(dy), F_.P(arg), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs,
+            F_.P(dx_s), None, 0, None, None, F_.stream())
     H.assert_close(dx_g, dx_s, tol=1e-6, what="pool backward: gather form == atomic scatter form")
     assert torch.equal(dx_g, dx_r), "pool backward: precomputed reverse positions change the result"
     assert int((topo.rev_pos == 0xFF).sum()) == 0, "symmetric graph: every edge has its reverse"

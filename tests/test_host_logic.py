@@ -103,10 +103,33 @@ def test_abi_accepts_an_empty_batch_without_a_gpu():
     from jova_amd import _lib
     tok = ctypes.c_void_p(16)                                    # non-null stand-in for the per-batch tables (never read)
     _lib.call("jova_graphconv_fwd", None, 0, 64, 0, 64, 64, tok, tok, tok, tok, 1, None, None, tok, None, None)
-    _lib.call("jova_graphpool_fwd", None, 0, 64, tok, tok, None, None, None)
-    _lib.call("jova_graphpool_bwd", None, None, 0, 64, tok, tok, None, None, 0, None, None)
+    _lib.call("jova_graphpool_fwd", None, 0, 64, tok, tok, None, None, None, None)
+    _lib.call("jova_graphpool_bwd", None, None, 0, 64, tok, tok, None, None, 0, None, None, None)
     with pytest.raises(RuntimeError, match="null pointer"):     # ... but not when there are atoms
-        _lib.call("jova_graphpool_fwd", None, 5, 64, tok, tok, None, None, None)
+        _lib.call("jova_graphpool_fwd", None, 5, 64, tok, tok, None, None, None, None)
+
+
+def test_block_order_is_a_permutation_with_one_eighth_of_every_bucket_per_xcd():
+    """jova_block_order (host-only): a permutation of the 16-row blocks; workgroup b (XCD b % 8) gets blocks whose
+    relative position inside their degree bucket lies in the (b % 8)-th eighth."""
+    from jova_amd import _lib
+    ds = np.array([[0, 0], [0, 1000], [1000, 3000], [4000, 2500], [6500, 700]] + [[7200, 0]] * 6, dtype=np.int64)
+    for n in (7200, 7193, 16, 1):
+        d = ds.copy()
+        if n < 7200:
+            d[4, 1] -= 7200 - n if n > 6500 else 0
+        if n <= 16:
+            d = np.array([[0, 0], [0, n]] + [[n, 0]] * 9, dtype=np.int64)
+        nb = (n + 15) // 16
+        o = np.full(nb, -1, dtype=np.int32)
+        _lib.call("jova_block_order", ctypes.c_void_p(d.ctypes.data), n, ctypes.c_void_p(o.ctypes.data))
+        assert sorted(o.tolist()) == list(range(nb))
+        if n == 7200:
+            for b in range(nb):
+                row0 = 16 * int(o[b])
+                k = [i for i in range(11) if d[i, 0] <= row0 < d[i, 0] + d[i, 1]][0]
+                rel = (row0 - d[k, 0]) / float(d[k, 1])
+                assert (b % 8) / 8.0 - 0.02 <= rel <= (b % 8 + 1) / 8.0 + 0.02, (b, row0, rel)
 
 
 def test_state_dict_matches_reference_manifest():
