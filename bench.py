@@ -199,12 +199,12 @@ def graph_stress(device, reps=20, full=True):
         dws = torch.empty(int(lib().jova_graphconv_bwd_scratch_floats()), device=device)
         timed("graphconv_bwd_l1(dW only)",
               lambda: call("jova_graphconv_bwd", P(x1), 0, x1.shape[1], n, 75, 64, ds, adj, pw1, P(dz), None, pdw1, pdb1,
-                           None, None, P(topo.sym_flag), dsh, P(dws), st),
+                           None, None, P(topo.sym_flag), dsh, P(dws), None, st),
               4 * (n * 64 + n * 75 + e) + 2 * 4 * 21 * 76 * 64,
               kernels=("graphconv_bwd_dma_kernel<10, false, false, 4, false>", "graphconv_dw_fold_kernel"), launches=3)
         timed("graphconv_bwd_l2(dW + dX, 2 launches)",
               lambda: call("jova_graphconv_bwd", P(x2), 0, 64, n, 64, 64, ds, adj, pw2, P(dz), None, pdw2, pdb2, P(dx),
-                           P(gbuf), P(topo.sym_flag), dsh, None, st),
+                           P(gbuf), P(topo.sym_flag), dsh, None, order, st),
               4 * (n * 64 + 3 * n * 64 + e) + 2 * wbytes, launches=2,
               kernels=("graphconv_bwd_dma_kernel<8, true, false, 4, false>", "graphconv_bwd_dx_v4_kernel"))
         timed("graphpool_bwd(64)", lambda: call("jova_graphpool_bwd", P(dz), P(arg), n, 64, ds, adj, P(dx),

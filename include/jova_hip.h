@@ -51,12 +51,13 @@ size_t jova_graphconv_workspace_floats(int f_in, int f_out);
  * dweight/dbias: HOST arrays of 21 device pointers, accumulate.  dx [N, f_in] (optional, fp32 atoms only) needs
  * gbuf [N, f_in] scratch and `weight`.  sym_flag: device int from jova_adj_symmetry (NULL or 0 -> atomic scatter).
  * deg_slice_host: optional HOST copy of deg_slice (the collator has it: mol_graphs.py:304-314); with it the work is
- * split on the host into equally long workgroups that are all resident at once, without it into fixed tile groups. */
+ * split on the host into equally long workgroups that are all resident at once, without it into fixed tile groups.
+ * block_order (optional): as in jova_graphpool_fwd, for the neighbour-gather launch of dx. */
 int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t ld_atoms, int64_t n_atoms, int f_in, int f_out,
                        const int64_t* deg_slice, const int32_t* const* adj, const float* const* weight,
                        const float* dy, const float* y_or_null, float* const* dweight, float* const* dbias,
                        float* dx_or_null, float* gbuf_or_null, const int* sym_flag, const int64_t* deg_slice_host,
-                       float* dw_scratch_or_null, void* stream);
+                       float* dw_scratch_or_null, const int32_t* block_order_or_null, void* stream);
 /* floats of the optional `dw_scratch` above: an aligned image of the 21 weight gradients that the kernel accumulates in
  * when f_in is not a multiple of 32 (rows of 75 floats straddle 128-byte lines and slow the float atomics 10x);
  * contents on entry are ignored, the result is added to dweight by a fold kernel. */

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("JOVA_LIB") or os.path.join(_HERE, "libjova_hip.so")  
 _SIGS = {
     "jova_graphconv_fwd": "piqqiipppp" + "ippppp",
     "jova_atoms_to_f32": "pqiipp",
-    "jova_graphconv_bwd": "piqqiippp" + "pppp" + "pppppp",
+    "jova_graphconv_bwd": "piqqiippp" + "pppp" + "ppppppp",
     "jova_adj_symmetry": "qpppp",
     "jova_graphpool_fwd": "pqipp" + "pppp",
     "jova_block_order": "pqp",

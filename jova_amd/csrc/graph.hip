@@ -1238,7 +1238,8 @@ graphconv_bwd_dma_kernel(const float* __restrict__ x, int n_atoms, int ldx, int 
 // Symmetric adjacency: a gather over i's own list; otherwise the scatter with float atomics.
 __global__ void __launch_bounds__(256)
 graphconv_bwd_dx_v4_kernel(int n_atoms, int f, const long long* __restrict__ deg_slice, GcParams P,
-                           const float* __restrict__ gbuf, float* __restrict__ dx, const int* __restrict__ sym_flag);
+                           const float* __restrict__ gbuf, float* __restrict__ dx, const int* __restrict__ sym_flag,
+                           const int* __restrict__ order);
 
 // flag <- 1 iff every neighbour list is duplicate-free, self-loop-free and i in nbr(j) whenever j in nbr(i)
 __global__ void adj_symmetry_kernel(int n_atoms, const long long* __restrict__ deg_slice, GcParams P,
@@ -1574,9 +1575,10 @@ graphpool_bwd_v5_kernel(const float* __restrict__ dy, const unsigned char* __res
 
 __global__ void __launch_bounds__(256)
 graphconv_bwd_dx_v4_kernel(int n_atoms, int f, const long long* __restrict__ deg_slice, GcParams P,
-                           const float* __restrict__ gbuf, float* __restrict__ dx, const int* __restrict__ sym_flag) {
+                           const float* __restrict__ gbuf, float* __restrict__ dx, const int* __restrict__ sym_flag,
+                           const int* __restrict__ order) {
     const int l16 = threadIdx.x & 15;
-    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long long row = (long long)ordered_block(order) * 16 + (threadIdx.x >> 4);
     if (row >= n_atoms) return;
     int deg;
     long long lrow;
@@ -1944,7 +1946,7 @@ extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t l
                                   const float* const* weight, const float* dy, const float* y_or_null,
                                   float* const* dweight, float* const* dbias, float* dx_or_null, float* gbuf_or_null,
                                   const int* sym_flag, const int64_t* deg_slice_host, float* dw_scratch_or_null,
-                                  void* stream) {
+                                  const int32_t* block_order_or_null, void* stream) {
     JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 31), "graphconv_bwd: n_atoms out of range");
     JOVA_CHECK_ARG(f_in >= 1 && f_in <= 128, "graphconv_bwd: f_in %d not in [1,128]", f_in);
     JOVA_CHECK_ARG(f_out >= 1 && f_out <= 64, "graphconv_bwd: f_out %d not in [1,64]", f_out);
@@ -2010,7 +2012,7 @@ extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t l
         if (dx_or_null) {
             JOVA_CHECK_ARG(sym_flag, "graphconv_bwd: sym_flag is null");
             hipLaunchKernelGGL(graphconv_bwd_dx_v4_kernel, dim3(cdiv(n_atoms, 16)), dim3(256), 0, s, (int)n_atoms, f_in,
-                               (const long long*)deg_slice, P, gbuf_or_null, dx_or_null, sym_flag);
+                               (const long long*)deg_slice, P, gbuf_or_null, dx_or_null, sym_flag, block_order_or_null);
             JOVA_CHECK_LAUNCH("graphconv_bwd_dx_v4");
         }
         return JOVA_OK;

@@ -202,7 +202,8 @@ class GraphConvFunction(torch.autograd.Function):
         call("jova_graphconv_bwd", P(xf), 0, ld, n, f_in, f_out, P(topo.deg_slice), topo.adj_ptrs,
              ptr_array(ctx.weights), P(dy), P(out) if mask else None, ptr_array(sink.targets[:21]),
              ptr_array(sink.targets[21:]), P(dx), P(gbuf), P(topo.sym_flag),
-             ctypes.c_void_p(topo.deg_slice_host.ctypes.data), P(dws), stream())
+             ctypes.c_void_p(topo.deg_slice_host.ctypes.data), P(dws), P(topo.block_order) if need_dx else None,
+             stream())
         return (dx, None, None, None) + tuple(sink.returns)
 
 
