@@ -107,7 +107,7 @@ def cpu_baseline(pool, hp, batch_ids, state_dict, n_steps, threads):
                        % (n_steps, hp["tr_batch_size"], med, t_col * 1e3))
 
 
-def graph_stress(device, reps=20, full=True):
+def graph_stress(device, reps=20, full=True, row_order_lines=True):
     """Config 4: 4096 molecules (~246 k atoms, degree <= 10): graph kernels against the HBM roofline.
 
     Every kernel is launched through the C ABI (jova_amd._lib.call) on pre-allocated buffers, `reps` launches back to
@@ -183,9 +183,10 @@ def graph_stress(device, reps=20, full=True):
     order = P(topo.block_order)
     timed("graphpool_fwd(64)", lambda: call("jova_graphpool_fwd", P(x2), n, 64, ds, adj, P(out), P(arg), order, st),
           4 * (2 * n * 64 + e) + n * 64, kernels=("graphpool_fwd_v4_kernel",))
-    timed("graphpool_fwd(64), blocks in row order",
-          lambda: call("jova_graphpool_fwd", P(x2), n, 64, ds, adj, P(out), P(arg), None, st),
-          4 * (2 * n * 64 + e) + n * 64, kernels=())
+    if row_order_lines:                                    # the same kernel without the XCD-aware block order
+        timed("graphpool_fwd(64), blocks in row order",
+              lambda: call("jova_graphpool_fwd", P(x2), n, 64, ds, adj, P(out), P(arg), None, st),
+              4 * (2 * n * 64 + e) + n * 64, kernels=())
     if full:
         # backward kernels accumulate into gradient buffers (as in the trainer).  In the model the BatchNorm behind
         # each convolution applies the backward of the convolution's ReLU (it reads that output anyway), so the
@@ -210,10 +211,11 @@ def graph_stress(device, reps=20, full=True):
         timed("graphpool_bwd(64)", lambda: call("jova_graphpool_bwd", P(dz), P(arg), n, 64, ds, adj, P(dx),
                                                 P(topo.sym_flag), sym, P(topo.rev_pos), order, st),
               4 * (2 * n * 64 + e) + n * 64, kernels=("graphpool_bwd_v5_kernel",))
-        timed("graphpool_bwd(64), blocks in row order",
-              lambda: call("jova_graphpool_bwd", P(dz), P(arg), n, 64, ds, adj, P(dx), P(topo.sym_flag), sym,
-                           P(topo.rev_pos), None, st),
-              4 * (2 * n * 64 + e) + n * 64, kernels=())
+        if row_order_lines:
+            timed("graphpool_bwd(64), blocks in row order",
+                  lambda: call("jova_graphpool_bwd", P(dz), P(arg), n, 64, ds, adj, P(dx), P(topo.sym_flag), sym,
+                               P(topo.rev_pos), None, st),
+                  4 * (2 * n * 64 + e) + n * 64, kernels=())
     if full:
         # GraphGather2D (contiguous chunks -> zero-padded [A_max, B, g]) and the nonsat activation on it, g = 128
         g = 128

@@ -3,4 +3,4 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
 import bench
-bench.graph_stress(torch.device('cuda:0'), reps=3, full=True)
+bench.graph_stress(torch.device('cuda:0'), reps=3, full=True, row_order_lines=False)
