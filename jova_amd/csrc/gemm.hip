@@ -52,8 +52,9 @@ template <bool VEC>
 __device__ __forceinline__ Quad load4(const float* __restrict__ base, long long off, int nvalid) {
     Quad q;
     q.nvalid = nvalid;
-    if (VEC) {      // VEC kernels are only launched when a quad is all-in or all-out
-        q.v = *reinterpret_cast<const float4*>(base + (nvalid >= 4 ? off : 0));
+    if (VEC) {      // VEC kernels are only launched when every quad that is partly inside the operand is readable as
+                    // a whole (a multiple-of-4 extent, or rows padded to one: the host checks); masked() drops the rest
+        q.v = *reinterpret_cast<const float4*>(base + (nvalid > 0 ? off : 0));
     } else {
         q.v.x = base[nvalid > 0 ? off : 0];
         q.v.y = base[nvalid > 1 ? off + 1 : 0];
@@ -567,10 +568,15 @@ extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
     g.alpha = alpha; g.relu = relu; g.splitk = splitk;
     const bool a_kc = (sak == 1), b_kc = (sbk == 1);
     const int64_t a_ld = a_kc ? sam : sak, b_ld = b_kc ? sbn : sbk;
-    // 16-byte loads need aligned quads that are entirely inside or outside the operand: the contiguous extent
-    // (K for a K-contiguous operand, M / N for a row-contiguous one) must be a multiple of 4 as well
-    const bool va = aligned16(A) && (a_ld % 4 == 0) && (sA1 % 4 == 0) && (sA2 % 4 == 0) && ((a_kc ? K : M) % 4 == 0);
-    const bool vb = aligned16(B) && (b_ld % 4 == 0) && (sB1 % 4 == 0) && (sB2 % 4 == 0) && ((b_kc ? K : N) % 4 == 0);
+    // 16-byte loads need aligned quads, and a quad that straddles the end of the contiguous extent (K for a
+    // K-contiguous operand, M / N for a row-contiguous one) must still lie inside the row: the extent is a multiple of
+    // 4, or the leading dimension covers the extent rounded up to 4 (padded rows, e.g. the attention probabilities
+    // [S, S4]); the elements past the extent are dropped after the load, whatever they hold
+    const int a_ext = a_kc ? K : M, b_ext = b_kc ? K : N;
+    const bool va = aligned16(A) && (a_ld % 4 == 0) && (sA1 % 4 == 0) && (sA2 % 4 == 0) &&
+                    (a_ext % 4 == 0 || a_ld >= ((a_ext + 3) & ~3));
+    const bool vb = aligned16(B) && (b_ld % 4 == 0) && (sB1 % 4 == 0) && (sB2 % 4 == 0) &&
+                    (b_ext % 4 == 0 || b_ld >= ((b_ext + 3) & ~3));
     g.vecA = va; g.vecB = vb;
     hipStream_t s = (hipStream_t)stream;
     static int fast_env = -1, trace_env = -1;

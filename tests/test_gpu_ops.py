@@ -51,6 +51,31 @@ def test_gemm_layouts(device, layout, shape):
     H.assert_close(C, want, tol=2e-6, what="gemm " + layout)
 
 
+@pytest.mark.parametrize("layout", ["kc", "rc"])
+def test_gemm_padded_rows_with_garbage_in_the_padding(device, layout):
+    """Operands whose rows are padded to a multiple of 4 floats (the attention probabilities [S, S4]) take the 16-byte
+    loads although the extent (278) is not a multiple of 4: whatever sits in the padding, NaN included, is dropped."""
+    from jova_amd.nn import functional as F_
+    g = torch.Generator().manual_seed(9)
+    nb, M, N, K, ld = 3, 278, 64, 278, 280
+    a = torch.randn(nb, M, K, generator=g)
+    b = torch.randn(nb, K, N, generator=g)
+    want = torch.einsum("xmk,xkn->xmn", a.double(), b.double()).float()
+    if layout == "kc":                                           # A[m, k] at m * ld + k
+        A = torch.full((nb, M, ld), float("nan"))
+        A[:, :, :K] = a
+        sam, sak, sA = ld, 1, M * ld
+    else:                                                        # A[m, k] at k * ld + m
+        A = torch.full((nb, K, ld), float("nan"))
+        A[:, :, :M] = a.transpose(1, 2)
+        sam, sak, sA = 1, ld, K * ld
+    A, B = A.to(device), b.contiguous().to(device)
+    C = torch.full((nb, M, N), float("nan"), device=device)
+    F_.gemm(F_._addr(A), sam, sak, F_._addr(B), N, 1, F_._addr(C), N, M, N, K, nb1=nb, sA=(sA, 0), sB=(K * N, 0),
+            sC=(M * N, 0))
+    H.assert_close(C, want, tol=2e-6, what="padded " + layout)
+
+
 def test_gemm_batched_strided_and_splitk(device):
     from jova_amd.nn import functional as F_
     g = torch.Generator().manual_seed(5)
