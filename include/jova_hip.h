@@ -109,7 +109,10 @@ int jova_mul(const float* a, const float* b, int64_t n, float* out, void* stream
  * C[z](m,n) = epi(alpha * sum_k A[z](m,k) B[z](k,n)), A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn] (one unit
  * stride each), epi: + bias[n], + residual[m*ldr+n], ReLU (relu = 1).  relu = 2 is the ReLU BACKWARD mask: residual is
  * not added, the result is zeroed where residual[m*ldr+n] <= 0.  splitk > 1: partial sums ADDED to C with atomics
- * (no residual / relu).  Batch z = z1*nb2 + z2, offsets z1*s?1 + z2*s?2 (residual shares C's batch strides). */
+ * (no residual / relu).  Batch z = z1*nb2 + z2, offsets z1*s?1 + z2*s?2 (residual shares C's batch strides).
+ * Operands are read with 16-byte loads when base, leading dimension and batch strides are multiples of 4 floats and
+ * the contiguous extent is one too, or the leading dimension covers the extent rounded up to 4 (padded rows): then
+ * the up to 3 floats past the extent of every row must be addressable; their values are ignored. */
 int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
                   int64_t ldc, int M, int N, int K, float alpha, const float* bias, const float* residual, int64_t ldr,
                   int relu, int splitk, int nb1, int nb2, int64_t sA1, int64_t sA2, int64_t sB1, int64_t sB2,
