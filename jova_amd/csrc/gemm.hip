@@ -648,7 +648,8 @@ extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
             const long long wgs = (long long)cdiv(M, ts) * cdiv(N, ts) * gz;
             // time estimate in units of one SIMD's work: all 1024 SIMDs busy, or one wave's share of a tile
             const double total = (double)wgs * ts * ts / 1024.0, alone = (double)ts * ts / w;
-            const double cost = (total > alone ? total : alone) * (w == 4 ? 1.0 : (w == 3 ? 1.06 : 1.15));
+            // (measured on the per-(b,h) attention products at S = 279: 96-tiles run at ~0.85 of the 128-tile rate)
+            const double cost = (total > alone ? total : alone) * (w == 4 ? 1.0 : (w == 3 ? 1.2 : 1.25));
             if (cost < best) { best = cost; Wsel = w; }
         }
     }
