@@ -15,6 +15,29 @@ from ..feat.mol_graphs import ConvMol
 from ..nn import functional as F_
 
 
+def adjacency_is_symmetric(deg_slice, adj_lists, n_atoms):
+    """Host restatement of jova_adj_symmetry: every neighbour index in range, no self loops, no duplicate neighbours,
+    and i in nbr(j) whenever j in nbr(i).  The collator has the lists on the host anyway; handing the answer to the
+    Topology spares the training step its one device->host read per batch."""
+    src_parts, dst_parts = [], []
+    for d, a in enumerate(adj_lists, start=1):
+        a = np.asarray(a)
+        if a.size == 0:
+            continue
+        start = int(deg_slice[d][0])
+        src_parts.append(np.repeat(np.arange(start, start + a.shape[0], dtype=np.int64), d))
+        dst_parts.append(a.reshape(-1).astype(np.int64))
+    if not src_parts:
+        return True
+    src, dst = np.concatenate(src_parts), np.concatenate(dst_parts)
+    if (dst < 0).any() or (dst >= n_atoms).any() or (src == dst).any():
+        return False
+    fwd = np.sort(src * n_atoms + dst)
+    if (fwd[1:] == fwd[:-1]).any():
+        return False
+    return bool(np.array_equal(fwd, np.sort(dst * n_atoms + src)))
+
+
 def process_gconv_view_data(mols, device):
     """list of ConvMol -> the reference's gconv input list with device tensors (data.py:291-296)."""
     mm = ConvMol.agglomerate_mols(mols)
@@ -60,6 +83,7 @@ def process_gconv_view_data(mols, device):
         topo = F_.Topology(deg_slice, glist[4:], n_atoms_lst, n)
         topo._mol_off = d32[o:o + len(n_atoms_lst) + 1]
         topo._deg_slice_host = ds_host
+        topo._sym_host = adjacency_is_symmetric(ds_host, adj, n)
         o += len(n_atoms_lst) + 1
         topo._block_order = d32[o:o + n_blocks]
         deg_slice._jova_topology = topo

@@ -777,6 +777,7 @@ def test_config4_graph_stack_vs_oracle(device):
     H.assert_close(o3, r3, tol=2e-5, what="conv2+pool")
     # pool backward: every dy element is routed to exactly one atom -> column sums are conserved
     topo = glist[1]._jova_topology
+    assert topo._sym_host is True and int(topo.sym_flag.item()) == 1      # the collator's host check == the device flag
     assert topo.symmetric
     dy = torch.randn_like(o2)
     arg = torch.empty(o2.shape, dtype=torch.uint8, device=device)

@@ -132,6 +132,46 @@ def test_block_order_is_a_permutation_with_one_eighth_of_every_bucket_per_xcd():
                 assert (b % 8) / 8.0 - 0.02 <= rel <= (b % 8 + 1) / 8.0 + 0.02, (b, row0, rel)
 
 
+def test_host_symmetry_check_matches_a_brute_force_restatement():
+    """collate.adjacency_is_symmetric (what the collator tells the Topology instead of a device->host read) against a
+    plain-Python restatement of the device kernel's rule, on the golden batch graph and on broken variants of it."""
+    from jova_amd.data.collate import adjacency_is_symmetric
+    z = H.load("index_hubs_b8")                                  # reference-made batch graph with degrees up to 10
+    ds = np.asarray(z["deg_slice"], dtype=np.int64)
+    adj = [np.asarray(z["adj_%d" % d], dtype=np.int32).reshape(-1, d) for d in range(1, 11)]
+    n = int(z["nodes"].shape[0])
+
+    def brute(adj_lists):
+        nbr = {}
+        for d, a in enumerate(adj_lists, start=1):
+            for r in range(a.shape[0]):
+                nbr[int(ds[d, 0]) + r] = [int(v) for v in a[r]]
+        for i, lst in nbr.items():
+            if len(set(lst)) != len(lst) or i in lst or any(j < 0 or j >= n for j in lst):
+                return False
+            if any(i not in nbr.get(j, []) for j in lst):
+                return False
+        return True
+
+    assert brute(adj) and adjacency_is_symmetric(ds, adj, n)
+    k = max(d for d in range(1, 11) if adj[d - 1].size)            # a populated bucket
+    for kind in ("self_loop", "duplicate", "one_way", "out_of_range"):
+        bad = [a.copy() for a in adj]
+        row0 = int(ds[k, 0])
+        if kind == "self_loop":
+            bad[k - 1][0, 0] = row0
+        elif kind == "duplicate" and k >= 2:
+            bad[k - 1][0, 1] = bad[k - 1][0, 0]
+        elif kind == "one_way":
+            others = [v for v in range(n) if v != row0 and v not in bad[k - 1][0]]
+            bad[k - 1][0, 0] = others[0]
+        elif kind == "out_of_range":
+            bad[k - 1][0, 0] = n
+        else:
+            continue
+        assert not brute(bad) and not adjacency_is_symmetric(ds, bad, n), kind
+
+
 def test_state_dict_matches_reference_manifest():
     """Same keys and shapes as the reference's create_integrated_net at the tuned config => .mod files load as is."""
     from jova_amd.train import TUNED_DAVIS_HPARAMS, count_parameters, create_integrated_net
