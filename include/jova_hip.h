@@ -98,10 +98,17 @@ int jova_gather2d_bwd(const float* dout, const int32_t* mol_off, int a_max, int 
 /* ---- nonsat_activation: jova/nn/models.py:458-478 -----------------------------------------------------------
  * Newton-style iteration whose trip count depends on a global mean; decided on the device in ONE launch.
  * out = y_final, dfac = d y_final / d x (= 1 / (y_prev^2 + 1)), n_eval_dev int32 [3] = (evaluations, arrivals,
- * timeout flag).  workspace: jova_nonsat_workspace_bytes(n) bytes.  Backward: dx = dout * dfac (jova_mul). */
+ * timeout flag).  workspace: jova_nonsat_workspace_bytes(n) bytes.  Backward: dx = dout * dfac (jova_mul).
+ * The launch is one workgroup per CU at most (capped by an occupancy query) with an in-kernel barrier whose spins are
+ * bounded: if the workgroups are not all resident (another process holds CUs) the give-up is collective, the flag
+ * n_eval_dev[2] is raised and the outputs of the workgroups that gave up are filled with NaN, so the failure reaches
+ * the loss / the non-finite check (proj/dti/train_joint_attn.py:468-470) instead of training on a torn tensor. */
 size_t jova_nonsat_workspace_bytes(int64_t n);
 int jova_nonsat_fwd(const float* x, int64_t n, float ep, int max_iter, float* out, float* dfac, int* n_eval_dev,
                     void* workspace, void* stream);
+/* spin bound of the barrier above in ticks of the 100 MHz wall clock (0 restores the default, 2 s); process-wide.
+ * No counterpart in the reference; tests use it to provoke the give-up path. */
+void jova_nonsat_set_spin_limit(uint64_t ticks);
 int jova_mul(const float* a, const float* b, int64_t n, float* out, void* stream);
 
 /* ---- dense contractions: nn.Linear / bmm call sites of jova/nn/models.py:740-771, :944-963, :996-998 and

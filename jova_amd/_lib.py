@@ -49,7 +49,8 @@ _SIGS = {
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "q": ctypes.c_int64, "f": ctypes.c_float, "Q": ctypes.c_uint64}
 
 EXPORTS = sorted(list(_SIGS) + ["jova_last_error", "jova_abi_version", "jova_nonsat_workspace_bytes",
-                                "jova_graphconv_workspace_floats", "jova_graphconv_bwd_scratch_floats"])
+                                "jova_graphconv_workspace_floats", "jova_graphconv_bwd_scratch_floats",
+                                "jova_nonsat_set_spin_limit"])
 
 _lib = None
 
@@ -75,6 +76,8 @@ def lib():
         L.jova_graphconv_workspace_floats.argtypes = [ctypes.c_int, ctypes.c_int]
         L.jova_graphconv_bwd_scratch_floats.restype = ctypes.c_size_t
         L.jova_graphconv_bwd_scratch_floats.argtypes = []
+        L.jova_nonsat_set_spin_limit.restype = None
+        L.jova_nonsat_set_spin_limit.argtypes = [ctypes.c_uint64]
         _lib = L
     return _lib
 

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -1241,6 +1242,8 @@ graphconv_bwd_dx_v4_kernel(int n_atoms, int f, const long long* __restrict__ deg
                            const float* __restrict__ gbuf, float* __restrict__ dx, const int* __restrict__ sym_flag,
                            const int* __restrict__ order);
 
+__global__ void set_int_kernel(int* p, int v) { *p = v; }
+
 // flag <- 1 iff every neighbour list is duplicate-free, self-loop-free and i in nbr(j) whenever j in nbr(i)
 __global__ void adj_symmetry_kernel(int n_atoms, const long long* __restrict__ deg_slice, GcParams P,
                                     int* __restrict__ flag) {
@@ -1685,7 +1688,7 @@ template <int VEC>
 __global__ void __launch_bounds__(NS_THREADS)
 nonsat_persistent_kernel(const float* __restrict__ x, float* __restrict__ ya, float* __restrict__ yb, long long n,
                          float ep, int max_iter, double* partial, int* ctrl, float* __restrict__ out,
-                         float* __restrict__ dfac) {
+                         float* __restrict__ dfac, int* __restrict__ n_eval_out, unsigned long long spin_limit) {
     __shared__ double red[NS_THREADS / 64];
     __shared__ int s_flag;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1693,6 +1696,7 @@ nonsat_persistent_kernel(const float* __restrict__ x, float* __restrict__ ya, fl
     const long long stride = (long long)nb * NS_THREADS * VEC;
     const long long e0 = ((long long)blockIdx.x * NS_THREADS + tid) * VEC;
     int evals = 0;
+    bool failed = false;
     for (int it = 0;; ++it) {
         const float* yin = (it & 1) ? yb : ya;
         float* yout = (it & 1) ? ya : yb;
@@ -1727,16 +1731,25 @@ nonsat_persistent_kernel(const float* __restrict__ x, float* __restrict__ ya, fl
             __hip_atomic_fetch_add(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int want = (it + 1) * nb;
             const unsigned long long t0 = wall_clock64();
+            // The give-up is COLLECTIVE: whoever runs out of patience raises ctrl[2]; every spinner polls it, and everyone
+            // looks at it once more after the match, so no workgroup iterates on alone.  A workgroup that leaves this way
+            // poisons its share of the outputs (NaN) below: a torn activation cannot flow into training unnoticed.
             int ok = 1;
             while (__hip_atomic_load(&ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                if (__hip_atomic_load(&ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
                 __builtin_amdgcn_s_sleep(2);
-                if (wall_clock64() - t0 > 200000000ull) { ok = 0; break; }     // 2 s at 100 MHz: give up
+                if (wall_clock64() - t0 > spin_limit) {                        // default 2 s at 100 MHz
+                    __hip_atomic_store(&ctrl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
             }
+            if (ok && __hip_atomic_load(&ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ok = 0;
             s_flag = ok;
         }
         __syncthreads();
         if (!s_flag) {
-            if (tid == 0) __hip_atomic_store(&ctrl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            failed = true;
             evals = it + 1;
             break;
         }
@@ -1754,7 +1767,19 @@ nonsat_persistent_kernel(const float* __restrict__ x, float* __restrict__ ya, fl
         const float mean = (float)(tot / (double)n);
         if (mean <= ep || it > max_iter) { evals = it + 1; break; }
     }
-    if (blockIdx.x == 0 && tid == 0) ctrl[0] = evals;
+    if (tid == 0) {
+        if (blockIdx.x == 0) {
+            n_eval_out[0] = evals;
+            n_eval_out[1] = __hip_atomic_load(&ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (failed) n_eval_out[2] = 1;           // (zeroed by the host wrapper; only ever raised)
+    }
+    if (failed) {
+        const float qnan = __builtin_nanf("");
+        for (long long e = e0; e < n; e += stride)
+            for (int u = 0; u < VEC; ++u) { out[e + u] = qnan; dfac[e + u] = qnan; }
+        return;
+    }
     // evaluation evals-1 wrote (evals-1 even ? yb : ya); its input y_prev is x (evals == 1) or the other buffer
     const bool res_in_b = ((evals - 1) & 1) == 0;
     const float* yr = res_in_b ? yb : ya;
@@ -2040,8 +2065,8 @@ extern "C" int jova_adj_symmetry(int64_t n_atoms, const int64_t* deg_slice, cons
                                  void* stream) {
     JOVA_CHECK_ARG(deg_slice && adj && flag, "adj_symmetry: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    const int one = 1;
-    JOVA_CHECK_HIP(hipMemcpyAsync(flag, &one, sizeof(int), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, flag, 1);      // (no host memory in the stream: capturable)
+    JOVA_CHECK_LAUNCH("adj_symmetry_init");
     if (n_atoms == 0) return JOVA_OK;
     GcParams P;
     fill_params(P, adj, nullptr, nullptr);
@@ -2175,11 +2200,28 @@ extern "C" size_t jova_nonsat_workspace_bytes(int64_t n) {
     return 64 + sizeof(double) * 2 * NS_MAX_BLOCKS + sizeof(float) * 2 * (size_t)(n > 0 ? n : 0);
 }
 
-extern "C" int jova_nonsat_fwd(const float* x, int64_t n, float ep, int max_iter, float* out, float* dfac,
-                               int* n_eval_dev, void* workspace, void* stream) {
-    JOVA_CHECK_ARG(x && out && dfac && n_eval_dev && workspace && n >= 0, "nonsat_fwd: bad argument");
-    JOVA_CHECK_ARG(max_iter >= 0 && max_iter <= 100000, "nonsat_fwd: max_iter %d", max_iter);
-    hipStream_t s = (hipStream_t)stream;
+static unsigned long long g_ns_spin_limit = 200000000ull;      // ticks of the 100 MHz wall clock: 2 s
+extern "C" void jova_nonsat_set_spin_limit(uint64_t ticks) { g_ns_spin_limit = ticks ? ticks : 200000000ull; }
+
+// Workgroups the in-kernel barrier may use: one per CU, and never more than the occupancy query says fit at once.
+template <int VEC>
+static int nonsat_block_cap(int* cap) {
+    static int cached = 0;
+    if (cached == 0) {
+        int per_cu = 0;
+        JOVA_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nonsat_persistent_kernel<VEC>, NS_THREADS, 0));
+        if (per_cu < 1) {
+            jova_set_error("nonsat_fwd: the persistent kernel does not fit a CU (occupancy query returned %d)", per_cu);
+            return JOVA_ERR_LIMIT;
+        }
+        cached = g_num_cu < NS_MAX_BLOCKS ? g_num_cu : NS_MAX_BLOCKS;
+    }
+    *cap = cached;
+    return JOVA_OK;
+}
+
+static int nonsat_launch(const float* x, int64_t n, float ep, int max_iter, float* out, float* dfac, int* n_eval_dev,
+                         void* workspace, hipStream_t s) {
     JOVA_CHECK_HIP(num_cu_cached());
     // workspace: ctrl[16 ints] | partial[2][NS_MAX_BLOCKS] doubles | ya[n] | yb[n]
     int* ctrl = (int*)workspace;
@@ -2187,22 +2229,32 @@ extern "C" int jova_nonsat_fwd(const float* x, int64_t n, float ep, int max_iter
     float* ya = (float*)((char*)workspace + 64 + sizeof(double) * 2 * NS_MAX_BLOCKS);
     float* yb = ya + n;
     JOVA_CHECK_HIP(hipMemsetAsync(workspace, 0, 64 + sizeof(double) * 2 * NS_MAX_BLOCKS, s));
+    JOVA_CHECK_HIP(hipMemsetAsync(n_eval_dev, 0, 3 * sizeof(int), s));
     if (n == 0) return JOVA_OK;
-    // one workgroup per CU at most: every workgroup is resident, which the in-kernel barrier needs
+    // one workgroup per CU at most, capped by the occupancy query: every workgroup is resident at once, which the
+    // in-kernel barrier needs (a plain launch: the call stays capturable into a hipGraph)
     const bool vec4 = (n & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)out) | ((uintptr_t)dfac) | ((uintptr_t)ya)) & 15) == 0;
     const long long per_block = (long long)NS_THREADS * (vec4 ? 4 : 1);
     int blocks = (int)((n + per_block - 1) / per_block);
-    const int cap = g_num_cu < NS_MAX_BLOCKS ? g_num_cu : NS_MAX_BLOCKS;
+    int cap = 0;
+    const int rc = vec4 ? nonsat_block_cap<4>(&cap) : nonsat_block_cap<1>(&cap);
+    if (rc != JOVA_OK) return rc;
     if (blocks > cap) blocks = cap;
     if (vec4)
         hipLaunchKernelGGL(nonsat_persistent_kernel<4>, dim3(blocks), dim3(NS_THREADS), 0, s, x, ya, yb, (long long)n, ep,
-                           max_iter, partial, ctrl, out, dfac);
+                           max_iter, partial, ctrl, out, dfac, n_eval_dev, g_ns_spin_limit);
     else
         hipLaunchKernelGGL(nonsat_persistent_kernel<1>, dim3(blocks), dim3(NS_THREADS), 0, s, x, ya, yb, (long long)n, ep,
-                           max_iter, partial, ctrl, out, dfac);
+                           max_iter, partial, ctrl, out, dfac, n_eval_dev, g_ns_spin_limit);
     JOVA_CHECK_LAUNCH("nonsat_persistent");
-    JOVA_CHECK_HIP(hipMemcpyAsync(n_eval_dev, ctrl, 3 * sizeof(int), hipMemcpyDeviceToDevice, s));
     return JOVA_OK;
+}
+
+extern "C" int jova_nonsat_fwd(const float* x, int64_t n, float ep, int max_iter, float* out, float* dfac,
+                               int* n_eval_dev, void* workspace, void* stream) {
+    JOVA_CHECK_ARG(x && out && dfac && n_eval_dev && workspace && n >= 0, "nonsat_fwd: bad argument");
+    JOVA_CHECK_ARG(max_iter >= 0 && max_iter <= 100000, "nonsat_fwd: max_iter %d", max_iter);
+    return nonsat_launch(x, n, ep, max_iter, out, dfac, n_eval_dev, workspace, (hipStream_t)stream);
 }
 
 extern "C" int jova_mul(const float* a, const float* b, int64_t n, float* out, void* stream) {

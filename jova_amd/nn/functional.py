@@ -264,6 +264,14 @@ class NonsatFunction(torch.autograd.Function):
 
     last_n_eval = None          # device int32 [3] of the most recent call (evaluations, arrivals, timeout flag)
 
+    @classmethod
+    def raise_if_timed_out(cls):
+        """Reads the most recent call's give-up flag (ONE device->host read: call it off the hot loop, e.g. once per
+        epoch as Trainer.check_health does).  The kernel also NaN-fills what it gave up on, so the loss trips first."""
+        if cls.last_n_eval is not None and int(cls.last_n_eval[2].item()) != 0:
+            raise RuntimeError("jova_nonsat_fwd: the in-kernel barrier gave up (workgroups not co-resident: is another "
+                               "process using this GPU?); its outputs were poisoned with NaN")
+
     @staticmethod
     def forward(ctx, x, ep, max_iter):
         x = _c(x)

@@ -115,6 +115,36 @@ class FlatParameters(object):
         self.grad.zero_()
 
 
+class GradAllReduce(object):
+    """Sum of a flat fp32 gradient tensor over the ranks of ``process_group``.
+
+    RCCL ("nccl" backend) reduces the device buffer in place over xGMI: the production path, one process per GPU.
+    With the gloo backend (CPU rehearsal; several ranks sharing ONE GPU on a development box, which RCCL refuses) the
+    buffer is staged through pinned host memory and reduced there: gloo's own handling of device tensors did not
+    complete on this image, and this keeps the N-rank flow testable with the real kernels."""
+
+    def __init__(self, process_group=None):
+        self.pg = process_group
+        self.backend = torch.distributed.get_backend(process_group)
+        self._host = None
+        self.host_staged = self.backend == "gloo" and not os.environ.get("JOVA_GLOO_DEVICE_TENSORS")
+
+    def supports_async(self, t):
+        return not (self.host_staged and t.is_cuda)
+
+    def __call__(self, t, async_op=False):
+        if t.is_cuda and self.host_staged:
+            if self._host is None or self._host.numel() < t.numel():
+                self._host = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
+            h = self._host[:t.numel()]
+            h.copy_(t.reshape(-1), non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            torch.distributed.all_reduce(h, group=self.pg)
+            t.reshape(-1).copy_(h, non_blocking=True)
+            return None
+        return torch.distributed.all_reduce(t, group=self.pg, async_op=async_op)
+
+
 class OverlappedGradSync(object):
     """Gradient all-reduce of the flat buffer in two pieces, the first one overlapped with the rest of the backward.
 
@@ -124,8 +154,9 @@ class OverlappedGradSync(object):
     runs it on its own stream, ordered behind the kernels enqueued so far) while the encoders' backward still runs;
     the small first slice follows after backward.  Same sums as one all-reduce of the whole buffer."""
 
-    def __init__(self, flat, split, process_group=None):
+    def __init__(self, flat, split, process_group=None, reducer=None):
         self.flat, self.split, self.pg = flat, int(split), process_group
+        self.reduce = reducer if reducer is not None else GradAllReduce(process_group)
         self.work = None
 
     def watch(self, tensors):
@@ -137,16 +168,16 @@ class OverlappedGradSync(object):
 
     def _fire(self, grad):
         if self.work is None and self.split < self.flat.grad.numel():
-            self.work = torch.distributed.all_reduce(self.flat.grad[self.split:], group=self.pg, async_op=True)
+            self.work = self.reduce(self.flat.grad[self.split:], async_op=True)
         return grad
 
     def finish(self):
         """After backward: reduce what is left and wait for the early piece."""
         if self.work is None:
-            torch.distributed.all_reduce(self.flat.grad, group=self.pg)
+            self.reduce(self.flat.grad)
             return
         if self.split > 0:
-            torch.distributed.all_reduce(self.flat.grad[:self.split], group=self.pg)
+            self.reduce(self.flat.grad[:self.split])
         self.work.wait()
         self.work = None
 
@@ -187,10 +218,12 @@ class Trainer(object):
         self.sync = None
         # (force_sync: run the collectives of the N-rank step on a one-rank group -- rehearsal on a one-GPU box)
         self.collective = world_size > 1 or force_sync
-        if self.collective and not os.environ.get("JOVA_NO_OVERLAP"):   # knob: one all-reduce after backward
+        self.reduce = GradAllReduce(process_group) if self.collective else None
+        # overlap knob: JOVA_NO_OVERLAP=1 -> one all-reduce after backward (also what a host-staged reduction does)
+        if self.collective and not os.environ.get("JOVA_NO_OVERLAP") and self.reduce.supports_async(self.flat.grad):
             split = encoder_param_split(model, self.flat)
             if split is not None:
-                self.sync = OverlappedGradSync(self.flat, split, process_group)
+                self.sync = OverlappedGradSync(self.flat, split, process_group, self.reduce)
         if self.opt == "adamax":
             self.exp_avg = torch.zeros_like(self.flat.data)
             self.exp_inf = torch.zeros_like(self.flat.data)
@@ -217,7 +250,7 @@ class Trainer(object):
             if self.sync is not None:
                 self.sync.finish()                                            # RCCL sums; mean via scale
             else:
-                torch.distributed.all_reduce(self.flat.grad, group=self.pg)
+                self.reduce(self.flat.grad)
             scale = 1.0 / self.world_size
         self.step_idx += 1
         f = self.flat

@@ -265,6 +265,32 @@ def test_nonsat_iteration_cap(device):
     H.assert_close(out, want, tol=1e-5)
 
 
+def test_nonsat_barrier_give_up_is_visible(device):
+    """A barrier that gives up (workgroups not co-resident) must not hand a torn tensor to training: with the spin
+    bound cut to one tick the first arrivals give up, every workgroup follows (collective), the flag is raised and the
+    outputs are NaN; NonsatFunction.raise_if_timed_out reports it.  The next call with the default bound is clean."""
+    from jova_amd import _lib
+    from jova_amd.nn import functional as F_
+    from oracle import nn_ref as R
+    x = torch.randn(64 * 4096 * 8, generator=torch.Generator().manual_seed(3)) * 2
+    xd = x.to(device)
+    _lib.lib().jova_nonsat_set_spin_limit(1)
+    try:
+        out = F_.NonsatFunction.apply(xd, 1e-4, 100)
+        ctrl = F_.NonsatFunction.last_n_eval.cpu().tolist()
+    finally:
+        _lib.lib().jova_nonsat_set_spin_limit(0)
+    assert ctrl[2] == 1, "give-up flag not raised: %s" % ctrl
+    assert torch.isnan(out).any(), "a barrier that gave up must poison its outputs"
+    with pytest.raises(RuntimeError, match="barrier gave up"):
+        F_.NonsatFunction.raise_if_timed_out()
+    out = F_.NonsatFunction.apply(xd, 1e-4, 100)
+    want, n_eval = R.nonsat(x)
+    assert F_.NonsatFunction.last_n_eval.cpu().tolist() [0] == n_eval and F_.NonsatFunction.last_n_eval.cpu().tolist()[2] == 0
+    F_.NonsatFunction.raise_if_timed_out()
+    H.assert_close(out, want, tol=1e-5)
+
+
 # ------------------------------------------------------------------------------------------------ protein branch
 def test_prot2vec_vs_reference_golden(device):
     from jova_amd.nn.models import Prot2Vec, _construct_embedding_indices

@@ -68,7 +68,7 @@ def _header_decls():
     text = open(os.path.join(ROOT, "include", "jova_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(jova_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(int|size_t|const char\*|void|int64_t)\s+(jova_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         args = m.group(3).strip()
         n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
         decls[m.group(2)] = n
