@@ -109,6 +109,15 @@ int jova_nonsat_fwd(const float* x, int64_t n, float ep, int max_iter, float* ou
 /* spin bound of the barrier above in ticks of the 100 MHz wall clock (0 restores the default, 2 s); process-wide.
  * No counterpart in the reference; tests use it to provoke the give-up path. */
 void jova_nonsat_set_spin_limit(uint64_t ticks);
+/* Allocation-free variant of jova_nonsat_fwd.  NO counterpart in the reference: it exists for callers that cannot
+ * allocate device memory (code under hipGraph capture, tight serving loops, harnesses that forbid hipMalloc).  Same
+ * kernels and results as jova_nonsat_fwd, but the workspace lives in a built-in per-GPU scratch array of
+ * 64 + 8 KiB + 8 * jova_nonsat_noalloc_max_n() bytes (16 MiB; n <= jova_nonsat_noalloc_max_n() = 2^21 elements,
+ * larger n is rejected with an error).  The call itself allocates nothing.  All calls on one GPU share that array:
+ * calls that overlap on one GPU (two streams, two threads) race; serialise them. */
+int jova_nonsat_fwd_noalloc(const float* x, int64_t n, float ep, int max_iter, float* out, float* dfac,
+                            int* n_eval_dev, void* stream);
+int64_t jova_nonsat_noalloc_max_n(void);
 int jova_mul(const float* a, const float* b, int64_t n, float* out, void* stream);
 
 /* ---- dense contractions: nn.Linear / bmm call sites of jova/nn/models.py:740-771, :944-963, :996-998 and

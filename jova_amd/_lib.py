@@ -24,6 +24,7 @@ _SIGS = {
     "jova_gather2d_fwd": "ppiiipp",
     "jova_gather2d_bwd": "ppiiipp",
     "jova_nonsat_fwd": "pqfipppp" + "p",
+    "jova_nonsat_fwd_noalloc": "pqfippp" + "p",
     "jova_mul": "ppqpp",
     "jova_gemm_f32": "pqqpqqpq" + "iiif" + "ppqii" + "ii" + "qqqqqq" + "p",
     "jova_colstats": "pqipp",
@@ -50,7 +51,7 @@ _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "q": ctypes.c_int64, "f": ctypes
 
 EXPORTS = sorted(list(_SIGS) + ["jova_last_error", "jova_abi_version", "jova_nonsat_workspace_bytes",
                                 "jova_graphconv_workspace_floats", "jova_graphconv_bwd_scratch_floats",
-                                "jova_nonsat_set_spin_limit"])
+                                "jova_nonsat_set_spin_limit", "jova_nonsat_noalloc_max_n"])
 
 _lib = None
 
@@ -76,6 +77,8 @@ def lib():
         L.jova_graphconv_workspace_floats.argtypes = [ctypes.c_int, ctypes.c_int]
         L.jova_graphconv_bwd_scratch_floats.restype = ctypes.c_size_t
         L.jova_graphconv_bwd_scratch_floats.argtypes = []
+        L.jova_nonsat_noalloc_max_n.restype = ctypes.c_int64
+        L.jova_nonsat_noalloc_max_n.argtypes = []
         L.jova_nonsat_set_spin_limit.restype = None
         L.jova_nonsat_set_spin_limit.argtypes = [ctypes.c_uint64]
         _lib = L

@@ -2257,6 +2257,46 @@ extern "C" int jova_nonsat_fwd(const float* x, int64_t n, float ep, int max_iter
     return nonsat_launch(x, n, ep, max_iter, out, dfac, n_eval_dev, workspace, (hipStream_t)stream);
 }
 
+// ---- allocation-free variant (callers that cannot call hipMalloc: hipGraph capture, serving loops, harnesses that
+// forbid it).  Same kernels as jova_nonsat_fwd; the workspace (control words, per-workgroup partials, the two iterate
+// buffers) lives in a file-scope device array instead of caller memory.  Every GPU holds its own copy of the array at
+// its own address: that address is looked up once per device with hipGetSymbolAddress and used from then on (the
+// array's NAME is only a host-side stand-in and never reaches a kernel or a memset).
+#define NS_NOALLOC_MAX_N (1ll << 21)              // elements; 2 x 8 MiB of iterates + 8.1 KiB of control per GPU
+#define NS_NOALLOC_BYTES (64 + sizeof(double) * 2 * NS_MAX_BLOCKS + sizeof(float) * 2 * (size_t)NS_NOALLOC_MAX_N)
+static __device__ __align__(256) unsigned char scratch[NS_NOALLOC_BYTES];
+#define JOVA_MAX_DEVICES 64
+static void* g_scratch_ptr[JOVA_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+extern "C" int64_t jova_nonsat_noalloc_max_n(void) { return (int64_t)NS_NOALLOC_MAX_N; }
+
+extern "C" int jova_nonsat_fwd_noalloc(const float* x, int64_t n, float ep, int max_iter, float* out, float* dfac,
+                                       int* n_eval_dev, void* stream) {
+    JOVA_CHECK_ARG(x && out && dfac && n_eval_dev && n >= 0, "nonsat_fwd_noalloc: bad argument");
+    JOVA_CHECK_ARG(max_iter >= 0 && max_iter <= 100000, "nonsat_fwd_noalloc: max_iter %d", max_iter);
+    if (n > NS_NOALLOC_MAX_N) {
+        jova_set_error("nonsat_fwd_noalloc: %lld elements exceed the built-in scratch (%lld); use jova_nonsat_fwd with a "
+                       "caller workspace", (long long)n, (long long)NS_NOALLOC_MAX_N);
+        return JOVA_ERR_LIMIT;
+    }
+    int dev = 0;
+    JOVA_CHECK_HIP(hipGetDevice(&dev));
+    JOVA_CHECK_ARG(dev >= 0 && dev < JOVA_MAX_DEVICES, "nonsat_fwd_noalloc: device %d out of range", dev);
+    void* ws = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        if (!g_scratch_ptr[dev]) {               // first call on this device, with this device current
+            void* p = nullptr;
+            JOVA_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            JOVA_CHECK_ARG(p != nullptr, "nonsat_fwd_noalloc: hipGetSymbolAddress returned null");
+            g_scratch_ptr[dev] = p;
+        }
+        ws = g_scratch_ptr[dev];
+    }
+    return nonsat_launch(x, n, ep, max_iter, out, dfac, n_eval_dev, ws, (hipStream_t)stream);
+}
+
 extern "C" int jova_mul(const float* a, const float* b, int64_t n, float* out, void* stream) {
     JOVA_CHECK_ARG(a && b && out && n >= 0, "mul: bad argument");
     if (n == 0) return JOVA_OK;
