@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the JOVA multi-view DTI training hot path on MI355X (contract: see the task statement / DESIGN.md).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: starts N rank processes itself, see launch_ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 A step = zero_grad -> forward -> MSELoss(out*w, y) -> backward -> (gradient all-reduce) -> SGD update of the tuned
@@ -45,14 +45,40 @@ WORKLOADS = {
 }
 
 
-def build_batches(pool, conv_mols, hp, device, n_batches, seed, prot2vec):
-    rng = np.random.RandomState(seed)
+EPOCH_PAIRS = {"davis": 25459, "kiba": 118000, "metz": 28245}     # training pairs of one epoch (0.8 of the data set)
+
+
+def build_batches(pool, conv_mols, hp, device, n_batches, prot2vec, shape, world, rank):
+    """The first ``n_batches`` batches of this rank's shard of a fixed synthetic epoch (ShardSampler: one seeded
+    permutation, disjoint shards, tail dropped), collated and resident in HBM."""
+    from jova_amd.data.sampler import ShardSampler
+    mi, pi, y, w = pool.epoch_pairs(EPOCH_PAIRS[shape], seed=1000)
+    sampler = ShardSampler(len(mi), world, rank, hp["tr_batch_size"], seed=1)
     out = []
-    for _ in range(n_batches):
-        mi, pi, y, w = pool.sample_pairs(rng, hp["tr_batch_size"])
-        out.append(collate_pairs(pool, conv_mols, mi, pi, y, w, device, prot2vec,
+    for idx in sampler.indices()[:n_batches]:
+        out.append(collate_pairs(pool, conv_mols, mi[idx], pi[idx], y[idx], w[idx], device, prot2vec,
                                  with_psc="psc" in hp["prot"]["model_types"]))
-    return out
+    return out, sampler
+
+
+def launch_ranks(n):
+    """``python bench.py --gpus N`` from a bare shell: this parent never touches the GPU; it starts N rank processes
+    (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1) that run this same file, and exits with their code.
+    JOVA_BENCH_SHARE_GPU=1 (development boxes with one GPU): the ranks share GPU 0 and reduce gradients over gloo
+    through pinned host memory -- a rehearsal of the N-rank flow, flagged as such in the JSON, not a measurement."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()                       # (counting devices does not initialise the GPU)
+    if n_dev < n and not os.environ.get("JOVA_BENCH_SHARE_GPU"):
+        raise SystemExit("--gpus %d but %d GPU(s) visible: one process per GPU (JOVA_BENCH_SHARE_GPU=1 rehearses the "
+                         "N-rank flow on one GPU over gloo)" % (n, n_dev))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def measured_traffic():
@@ -261,19 +287,26 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["JOVA_BENCH_WATCHDOG"]), exit=True)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     n_dev = torch.cuda.device_count()
-    if local_rank >= n_dev:
+    shared = bool(os.environ.get("JOVA_BENCH_SHARE_GPU")) and world > 1
+    if local_rank >= n_dev and not shared:
         raise SystemExit("rank %d has no GPU of its own (%d visible): one process per GPU" % (local_rank, n_dev))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_id = 0 if shared else local_rank
+    torch.cuda.set_device(dev_id)
+    device = torch.device("cuda", dev_id)
     # JOVA_BENCH_FORCE_DIST=1 (under torch.distributed.run --nproc-per-node 1): the N-rank flow -- RCCL group, overlapped
     # gradient all-reduce, barriers, max over ranks -- on a one-rank group; a rehearsal for one-GPU boxes
     dist_on = world > 1 or bool(os.environ.get("JOVA_BENCH_FORCE_DIST"))
     pg = None
     if dist_on:
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if shared:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=device)
         pg = torch.distributed.group.WORLD
 
     hp = dict(TUNED_DAVIS_HPARAMS)
@@ -284,9 +317,9 @@ def main():
     torch.manual_seed(1)                                   # identical initial weights on every rank
     model = create_integrated_net(hp, pool.protein_profile).to(device).train()
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    trainer = Trainer(model, hp, world_size=world, process_group=pg, force_sync=dist_on)
+    trainer = Trainer(model, hp, world_size=world, process_group=pg, force_sync=dist_on, rank=rank)
     prot2vec = model[0].models[2][0]
-    batches = build_batches(pool, conv_mols, hp, device, 8, seed=1000 + rank, prot2vec=prot2vec)
+    batches, sampler = build_batches(pool, conv_mols, hp, device, 8, prot2vec, shape, world, rank)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -311,6 +344,23 @@ def main():
     final_loss = float(loss.item())
     if not np.isfinite(final_loss):
         raise SystemExit("non-finite loss")
+    trainer.check_health()
+    comm = None
+    if dist_on:
+        # the step's one exchange, alone: all-reduce of the flat gradient buffer, 10 back to back between barriers
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            trainer.reduce(trainer.flat.grad)
+        sync_all()
+        t_ar = torch.tensor([(time.perf_counter() - t1) / 10], dtype=torch.float64, device=device)
+        trainer.reduce(t_ar) if shared else torch.distributed.all_reduce(t_ar, op=torch.distributed.ReduceOp.MAX)
+        t_ar = float(t_ar.item()) / (world if shared else 1)
+        nbytes = trainer.flat.grad.numel() * 4
+        comm = dict(backend=torch.distributed.get_backend(pg), rccl_ranks=world if not shared else 0,
+                    allreduce_bytes=nbytes, allreduce_us=round(t_ar * 1e6, 1),
+                    bus_gbs=round(2.0 * (world - 1) / max(world, 1) * nbytes / t_ar / 1e9, 2),
+                    overlapped=trainer.sync is not None)
 
     bsz = hp["tr_batch_size"]
     pairs_per_s = args.steps * bsz * world / elapsed
@@ -332,8 +382,14 @@ def main():
                             global_batch=bsz * world, parallelism="dp%d" % world,
                             trainable_params=count_parameters(model)),
                 final_loss=round(final_loss, 6), roofline=roofline)
+    line["config"]["sampler"] = ("ShardSampler: %d-pair synthetic epoch, %d disjoint shards, %d steps/epoch, tail dropped"
+                                 % (sampler.n_pairs, world, sampler.steps_per_epoch))
+    if comm is not None:
+        line["comm"] = comm
     if dist_on and world == 1:
         line["rehearsal"] = "N-rank flow on a one-rank RCCL group"
+    if shared:
+        line["rehearsal"] = "%d ranks SHARING one GPU, gradients reduced over gloo through host memory: not a measurement" % world
     if rank == 0 and world == 1:
         if not args.no_graph_stress:
             line["graph_roofline"] = graph_stress(device)

@@ -126,8 +126,9 @@ __device__ __forceinline__ float frag(const float* __restrict__ S, int row, int 
     return KC ? S[row * LDS_KC + k] : S[k * (32 * W + 4) + row];
 }
 
-template <bool A_KC, bool B_KC, bool VA, bool VB, int W>
-__global__ void __launch_bounds__(64 * W, W == 4 ? GEMM_WGS : 4)
+#define GEMM_FOLD 4          // k-tiles (of BK) per accumulation chain
+template <bool A_KC, bool B_KC, bool VA, bool VB, int W, bool FOLD = false>
+__global__ void __launch_bounds__(64 * W, FOLD ? 2 : (W == 4 ? GEMM_WGS : 4))
 gemm_f32_kernel(GemmArgs g) {
     constexpr int TS = 32 * W;
     __shared__ __attribute__((aligned(16))) float As[A_KC ? TS * LDS_KC : BK * (TS + 4)];
@@ -157,11 +158,19 @@ gemm_f32_kernel(GemmArgs g) {
     const int wm = wave * 32;
     const int i = lane & 31, h = lane >> 5;
 
-    f32x16 acc[W];
+    // Two-level summation: the MFMA accumulates its k-steps as one sequential fp32 chain; every GEMM_FOLD k-tiles the
+    // chain is folded into `tot` and restarted.  A long chain of same-sign, near-identical addends (the attention
+    // P.V product over ~750 identical padded tokens of a long-protein batch) otherwise picks up a rounding bias that
+    // grows linearly with K (1.3e-5 at K = 1065, five times torch's blocked CPU sum); folded chains are <= 128 long.
+    // FOLD instantiations (batched products with K > 512: the host picks them) pay 16 W registers for it.
+    f32x16 acc[W], tot[FOLD ? W : 1];
 #pragma unroll
     for (int b = 0; b < W; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            acc[b][r] = 0.f;
+            if (FOLD) tot[b][r] = 0.f;
+        }
 
     // Register prefetch: tile t+1 is loaded into registers while tile t is multiplied out of LDS.
     Quad va[4], vb[4];
@@ -187,6 +196,18 @@ gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int b = 0; b < W; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[b], acc[b], 0, 0, 0);
         }
+        if (FOLD && (t % GEMM_FOLD) == GEMM_FOLD - 1) {
+#pragma unroll
+            for (int b = 0; b < W; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { tot[b][r] += acc[b][r]; acc[b][r] = 0.f; }
+        }
+    }
+    if (FOLD) {
+#pragma unroll
+        for (int b = 0; b < W; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] += tot[b][r];
     }
 
     float* C = g.C + z1 * g.sC1 + z2 * g.sC2;
@@ -653,6 +674,9 @@ extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
             if (cost < best) { best = cost; Wsel = w; }
         }
     }
+    // long batched contractions (attention products of long-protein batches): folded accumulation chains, 128-tiles
+    const bool fold = K > 512 && (long long)nb1 * nb2 > 1 && splitk == 1 && va && vb;
+    if (fold) Wsel = 4;
     const long long ts = 32 * Wsel;
     // a lone small product with a long K (the FC head at M = 128): split K over otherwise idle CUs, partial sums
     // added onto a zeroed C (bias comes with split 0; ReLU / residual cannot apply to partial sums)
@@ -683,7 +707,13 @@ extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
         else if (vb) GEMM_W(AK, BK_, false, true);                            \
         else GEMM_W(AK, BK_, false, false);                                   \
     } while (0)
-    if (a_kc && b_kc) GEMM_VEC(true, true);
+#define GEMM_FOLDED(AK, BK_) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, true, true, 4, true>), grid, dim3(256), 0, s, g)
+    if (fold) {
+        if (a_kc && b_kc) GEMM_FOLDED(true, true);
+        else if (a_kc && !b_kc) GEMM_FOLDED(true, false);
+        else if (!a_kc && b_kc) GEMM_FOLDED(false, true);
+        else GEMM_FOLDED(false, false);
+    } else if (a_kc && b_kc) GEMM_VEC(true, true);
     else if (a_kc && !b_kc) GEMM_VEC(true, false);
     else if (!a_kc && b_kc) GEMM_VEC(false, true);
     else GEMM_VEC(false, false);

@@ -282,7 +282,7 @@ layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ r, c
 
 // ------------------------------------------------------------------------------------------------ softmax
 // One wave per row of length n (<= 64 * SM_MAXV), in place capable.
-#define SM_MAXV 16
+#define SM_MAXV 32          // rows to 2048 elements (long-protein batches: S = 1 + A_max + P_max up to ~1100)
 template <int SMV>
 __global__ void __launch_bounds__(256)
 softmax_fwd_kernel(const float* __restrict__ x, long long n_rows, int n, long long ld, float* __restrict__ y) {
@@ -519,8 +519,11 @@ extern "C" int jova_softmax_fwd(const float* x, int64_t n_rows, int n, int64_t l
     if (n <= 512)
         hipLaunchKernelGGL(softmax_fwd_kernel<8>, dim3(cdiv(n_rows, 4)), dim3(256), 0, (hipStream_t)stream, x,
                            (long long)n_rows, n, (long long)ld, y);
-    else
+    else if (n <= 1024)
         hipLaunchKernelGGL(softmax_fwd_kernel<16>, dim3(cdiv(n_rows, 4)), dim3(256), 0, (hipStream_t)stream, x,
+                           (long long)n_rows, n, (long long)ld, y);
+    else
+        hipLaunchKernelGGL(softmax_fwd_kernel<32>, dim3(cdiv(n_rows, 4)), dim3(256), 0, (hipStream_t)stream, x,
                            (long long)n_rows, n, (long long)ld, y);
     JOVA_CHECK_LAUNCH("softmax_fwd");
     return JOVA_OK;
@@ -534,8 +537,11 @@ extern "C" int jova_softmax_bwd(const float* p, const float* dp, const float* p_
     if (n <= 512)
         hipLaunchKernelGGL(softmax_bwd_kernel<8>, dim3(cdiv(n_rows, 4)), dim3(256), 0, (hipStream_t)stream, p, dp,
                            p_dropped_or_null, keep_scale, (long long)n_rows, n, (long long)ld, ds);
-    else
+    else if (n <= 1024)
         hipLaunchKernelGGL(softmax_bwd_kernel<16>, dim3(cdiv(n_rows, 4)), dim3(256), 0, (hipStream_t)stream, p, dp,
+                           p_dropped_or_null, keep_scale, (long long)n_rows, n, (long long)ld, ds);
+    else
+        hipLaunchKernelGGL(softmax_bwd_kernel<32>, dim3(cdiv(n_rows, 4)), dim3(256), 0, (hipStream_t)stream, p, dp,
                            p_dropped_or_null, keep_scale, (long long)n_rows, n, (long long)ld, ds);
     JOVA_CHECK_LAUNCH("softmax_bwd");
     return JOVA_OK;

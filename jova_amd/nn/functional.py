@@ -467,13 +467,23 @@ class ReLUFunction(torch.autograd.Function):
 
 
 class _DropoutState(object):
-    """Philox (seed, offset) bookkeeping: one offset per dropout call, seeded from torch's global seed."""
+    """Philox (seed, offset) bookkeeping: one offset per dropout call.  The key is torch's global seed mixed with a
+    per-rank stream id (set_dropout_stream; the Trainer passes its rank), so data-parallel ranks that share
+    ``torch.manual_seed`` (identical initial weights) still draw independent masks."""
     offset = 0
+    stream = 0
 
     @classmethod
     def next(cls):
         cls.offset += 1
-        return torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, cls.offset
+        seed = (torch.initial_seed() ^ (cls.stream * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+        return seed, cls.offset
+
+
+def set_dropout_stream(stream_id):
+    """Selects the dropout mask stream of this process (rank of a data-parallel job); restarts the offset counter."""
+    _DropoutState.stream = int(stream_id)
+    _DropoutState.offset = 0
 
 
 def dropout_apply(x2d_addr, rows, n, ld, p, seed, offset, out_addr):

@@ -116,6 +116,11 @@ SHAPES = {
                  atoms=lambda r, k: _clip_normal(r, 27, 6, 10, 56, k),
                  segs=lambda r, k: _clip_lognormal(r, 4.3, 0.6, 20, 376, k),
                  deg_cap=4, hub_frac=0.0),
+    # config 5 stress variant: long protein sequences, P_max = 1024 segments (protein 0 is pinned to exactly 1024)
+    "long1024": dict(n_mols=240, n_prots=48,
+                     atoms=lambda r, k: _clip_normal(r, 27, 6, 10, 56, k),
+                     segs=lambda r, k: np.concatenate([[1024], _clip_lognormal(r, 5.6, 0.8, 20, 1024, k - 1)]),
+                     deg_cap=4, hub_frac=0.0),
     "graph4k": dict(n_mols=4096, n_prots=1,
                     atoms=lambda r, k: r.randint(20, 101, size=k).astype(np.int64),
                     segs=lambda r, k: np.full(k, 20, dtype=np.int64),
@@ -151,6 +156,15 @@ class SyntheticPool(object):
             rng = np.random.RandomState(self._psc_seed + 7919)
             self._psc = rng.normal(size=(len(self.prot_names), 8421)).astype(np.float32)
         return self._psc
+
+    def epoch_pairs(self, n_pairs, seed=0):
+        """A fixed training set of ``n_pairs`` (drug, target, label) triples over this pool (KIBA-shaped: ~118 k pairs over
+        ~2 100 drugs x ~230 targets) -> (mol_ids, prot_ids, y [n,1], w [n,1]); sharded by
+        jova_amd.data.sampler.ShardSampler."""
+        rng = np.random.RandomState(seed)
+        mi = rng.randint(0, len(self.mols), size=n_pairs)
+        pi = rng.randint(0, len(self.prot_names), size=n_pairs)
+        return mi, pi, rng.normal(size=(n_pairs, 1)), np.ones((n_pairs, 1))
 
     def sample_pairs(self, rng, batch_size):
         """-> (mol_ids [B], prot_ids [B], y [B,1] float64, w [B,1] float64)."""

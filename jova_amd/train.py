@@ -205,7 +205,9 @@ def encoder_param_split(model, flat):
 class Trainer(object):
     """One training step = the body of the reference's batch loop (train_joint_attn.py:428-486), no host sync."""
 
-    def __init__(self, model, hparams, world_size=1, process_group=None, force_sync=False):
+    def __init__(self, model, hparams, world_size=1, process_group=None, force_sync=False, rank=0):
+        F_.set_dropout_stream(rank)             # ranks share torch.manual_seed (same weights) but not dropout masks
+        self.rank = rank
         self.model = model
         self.hp = hparams
         self.flat = FlatParameters(model)
@@ -229,6 +231,22 @@ class Trainer(object):
             self.exp_inf = torch.zeros_like(self.flat.data)
         elif self.opt != "sgd":
             raise NotImplementedError("optimizer %r: the HIP path implements sgd and adamax" % self.opt)
+
+    def check_health(self):
+        """Off the hot loop (the reference checks its loss every batch, train_joint_attn.py:468-470; here once per epoch
+        or at the end of a run): raises if the nonsat kernel's barrier ever gave up (one device->host read)."""
+        F_.NonsatFunction.raise_if_timed_out()
+
+    def sync_buffers(self):
+        """BatchNorm running statistics are per-rank (each rank normalises its own shard, as the reference would on that
+        shard).  Before a checkpoint is written they are averaged over the ranks, so the saved state does not depend on
+        which rank saves it (num_batches_tracked is identical on every rank)."""
+        if not self.collective or self.world_size == 1:
+            return
+        for name, buf in self.model.named_buffers():
+            if buf.is_floating_point():
+                self.reduce(buf.data)
+                buf.data.div_(self.world_size)
 
     def forward_loss(self, batch):
         if self.sync is None:

@@ -69,14 +69,11 @@ def graph_pool(atoms, deg_slice, adj_lists, max_deg=10):
 
 
 def gather2d(atoms, n_atoms_lst):
-    """layers.py:429-432: contiguous chunks of n_atoms rows, zero padded, stacked on dim 1 -> [A_max, B, g]."""
+    """layers.py:429-432: contiguous chunks of n_atoms rows, zero padded, stacked on dim 1 -> [A_max, B, g].
+    (split / pad / stack, as the reference: in-place slice assignment would chain one autograd node per molecule.)"""
     a_max = max(n_atoms_lst)
-    out = atoms.new_zeros((a_max, len(n_atoms_lst), atoms.shape[1]))
-    row = 0
-    for b, n in enumerate(n_atoms_lst):
-        out[:n, b, :] = atoms[row:row + n]
-        row += n
-    return out
+    chunks = torch.split(atoms, [int(n) for n in n_atoms_lst], dim=0)
+    return torch.stack([torch.nn.functional.pad(c, (0, 0, 0, a_max - c.shape[0])) for c in chunks], dim=1)
 
 
 def nonsat(x, ep=1e-4, max_iter=100):

@@ -78,3 +78,81 @@ def assert_close(a, b, tol=1e-5, what="", floor=0.0):
     assert a.shape == b.shape, "%s: shape %s vs %s" % (what, a.shape, b.shape)
     e = rel_err(a, b, floor)
     assert e <= tol, "%s: rel err %.3e > %.1e" % (what, e, tol)
+
+
+# ---------------------------------------------------------------------------------------------- full-size fixtures
+FULL_TAGS = ("davis_b128", "kiba_b128", "metz_psc_b128", "davis_b256_default", "long1024_b128")
+
+
+def full_setup(tag):
+    """Inputs of a tests/golden/full_<tag>.npz fixture (tools/make_golden_full.py), regenerated from its recorded seeds:
+    -> (z, spec, hparams in the train.py layout, pool, mol ids, protein ids, y, w)."""
+    from jova_amd import synth
+    z = load("full_" + tag)
+    spec = json.loads(str(z["spec"]))
+    hp = spec["hp"]
+    hparams = {"attn_heads": hp["heads"], "attn_layers": hp["attn_layers"], "lin_dims": hp["lin_dims"], "output_dim": 1,
+               "latent_dim": hp["latent"], "dprob": hp["dprob"], "optimizer": "sgd", "tr_batch_size": spec["batch"],
+               "optimizer__global__lr": 4.70e-3, "optimizer__global__weight_decay": 1.91e-2,
+               "prot": {"model_types": list(spec["views"]), "vocab_size": hp["vocab"], "window": hp["window"],
+                        "pcnn_num_layers": hp["pcnn_layers"], "embedding_dim": hp["emb"], "psc_dim": 8421},
+               "gconv": {"dim": hp["gconv_dim"]}, "ecfp8": {"dim": hp["ecfp_dim"]}}
+    pool = synth.SyntheticPool(spec["shape"], seed=spec["pool_seed"], n_mols=spec["n_mols"], n_prots=spec["n_prots"])
+    mi, pi, y, w = pool.sample_pairs(np.random.RandomState(spec["pair_seed"]), spec["batch"])
+    if spec["shape"] == "long1024":
+        pi[0] = 0
+    return z, spec, hparams, pool, mi, pi, y, w
+
+
+def full_net(spec, hparams, pool):
+    """The model of a full-size fixture with the weights the reference drew (same torch seed, same construction order);
+    check_full_weights proves it."""
+    from jova_amd.train import create_integrated_net
+    torch.manual_seed(spec["weight_seed"])
+    return create_integrated_net(hparams, pool.protein_profile)
+
+
+def check_full_weights(z, net):
+    for k, p in net.named_parameters():
+        want = z["wsum." + k]
+        bits = p.detach().cpu().reshape(-1).view(torch.int32).to(torch.int64)
+        got = np.array([int(bits.sum()), int((bits * (torch.arange(bits.numel()) % 8191 + 1)).sum())], dtype=np.int64)
+        assert np.array_equal(got, want), "initial weights differ from the reference's for %s: %s vs %s" % (k, got, want)
+
+
+def sample_index(numel, k=2048):
+    """The strided gradient sample of tools/make_golden_full.py."""
+    return np.unique(np.linspace(0, numel - 1, min(numel, k)).astype(np.int64))
+
+
+def check_full_grads(z, grads, what):
+    """grads: name -> float64 numpy gradient of the path under test.  Bound per tensor, derived from the reference's own
+    fp32 run: err(test, ref64) <= max(1e-5, 2 * err(ref32, ref64)), err = max|difference| / max|ref64| over the tensor
+    (the committed sample of ref64 for the element-wise part, the L2 norm for the whole tensor).  err(ref32, ref64) is the
+    largest over three fp32 runs of the reference that differ only in summation order (CPU thread count), and is taken
+    no smaller than the reference's whole-gradient distance L2(g32 - g64) / L2(g64) over all parameters: which borderline
+    ReLU masks flip is a coin toss per run, so one run's luck on one tensor is not a bound for another fp32 run.  Tensors whose
+    double-precision gradient is analytically zero (a bias in front of a BatchNorm, the affine of a LayerNorm in front of
+    one: < 1e-9 of the largest gradient) are judged on the absolute scale instead: |test| <= 1e-5 * largest gradient."""
+    gmax = max(float(z[k][1]) for k in z.files if k.startswith("gstat."))
+    stats = [z[k] for k in z.files if k.startswith("gstat.")]
+    e_all = float(np.sqrt(sum(float(s[3]) ** 2 for s in stats) / sum(float(s[0]) ** 2 for s in stats)))
+    worst = (0.0, "")
+    for k in z.files:
+        if not k.startswith("gstat."):
+            continue
+        name = k[len("gstat."):]
+        l2, mx, dmax, dl2 = (float(v) for v in z[k])
+        g = np.asarray(grads[name], dtype=np.float64).reshape(-1)
+        if mx < 1e-9 * gmax:
+            assert float(np.abs(g).max()) <= max(1e-5 * gmax, 2 * dmax), "%s %s: analytically zero gradient is %.3e" % (
+                what, name, float(np.abs(g).max()))
+            continue
+        bound = max(1e-5, 2 * max(dmax / mx, e_all))
+        e = float(np.abs(g[sample_index(g.size)] - z["gs64." + name]).max()) / mx
+        assert e <= bound, "%s %s: gradient sample err %.3e > %.3e (= max(1e-5, 2 x ref32-vs-ref64))" % (what, name, e, bound)
+        bound2 = max(1e-5, 2 * max(dl2 / l2, e_all))
+        e2 = abs(float(np.sqrt((g ** 2).sum())) - l2) / l2
+        assert e2 <= bound2, "%s %s: gradient L2 norm off by %.3e > %.3e" % (what, name, e2, bound2)
+        worst = max(worst, (e / bound, name))
+    return worst

@@ -1,0 +1,139 @@
+"""Full-size parity against fixtures made by the imported reference (tools/make_golden_full.py): the tuned Davis model
+at B = 128, KIBA- and Metz+PSC-shaped batches, the default-hparams model at B = 256 and a long-protein stress batch
+(P_max = 1024, S = 1065 tokens), each run by the reference in fp32 AND in double.
+
+Bound per tensor: err(x, ref64) <= max(1e-5, 2 * err(ref32, ref64)).  What the fixtures show: at these
+sizes the reference's own fp32 run sits 0.7 - 5e-5 from its double run on the outputs, and on the parameter gradients
+anywhere from 4e-5 (median, KIBA-shaped batch) to 8e-3 (median, Davis batch; single tensors to 1e-1): when one of the
+~10^5 pre-activations of the BatchNorm/ReLU stages lies within rounding of zero its mask flips, and one flipped sample
+moves a weight-gradient row by ~1/sqrt(B).  So 1e-5 is reachable only where the reference reaches it: op level
+(tests/test_gpu_ops.py goldens) and the outputs / loss here.
+
+CPU part: the fp64 oracle against the double run (no mask flips between two double runs: 1e-9).
+GPU part: the HIP path against the double run with the derived bounds; nonsat evaluation counts equal the reference's.
+"""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+
+def _oracle_run(tag, dtype=torch.float64):
+    from oracle import mol_graphs as og
+    from oracle import nn_ref as R
+    z, spec, hparams, pool, mi, pi, y, w = H.full_setup(tag)
+    net = H.full_net(spec, hparams, pool)
+    H.check_full_weights(z, net)
+    p = {k: (v.detach().to(dtype).requires_grad_("running" not in k) if v.is_floating_point() else v)
+         for k, v in net.state_dict().items()}
+    b = og.agglomerate([og.SortedMol(*pool.mols[i]) for i in mi])
+    gl = og.gconv_input_list(b)
+    glist = [torch.from_numpy(gl[0]), torch.from_numpy(gl[1]), torch.from_numpy(gl[2]), gl[3]] + \
+            [torch.from_numpy(a) for a in gl[4:]]
+    idx = og.embedding_indices([pool.prot_names[i] for i in pi], pool.protein_profile, fill_val=pool.vocab)
+    ob = dict(ecfp=torch.from_numpy(pool.ecfp[mi]).to(dtype), glist=glist, prot_idx=torch.from_numpy(idx),
+              psc=torch.from_numpy(pool.psc[pi]).to(dtype) if "psc" in spec["views"] else None)
+    hp = spec["hp"]
+    out, n_eval = R.dti_forward(p, ob, hp["heads"], hp["pcnn_layers"], len(hp["lin_dims"]))
+    loss = R.mse_loss(out, torch.from_numpy(w).to(dtype), torch.from_numpy(y).to(dtype))
+    loss.backward()
+    grads = {}
+    for k, v in p.items():
+        if torch.is_tensor(v) and v.requires_grad:
+            g = v.grad.detach().double().numpy().copy() if v.grad is not None else np.zeros(tuple(v.shape))
+            if k.endswith("embedding.weight"):
+                g[hp["vocab"]] = 0                          # nn.Embedding(padding_idx): that row gets no gradient
+            grads[k] = g
+    return z, out.detach().double().numpy(), float(loss), n_eval, grads
+
+
+@pytest.mark.parametrize("tag", ["davis_b128", "metz_psc_b128"])
+def test_oracle_fp64_equals_reference_double_run_at_full_size(tag):
+    torch.set_num_threads(8)
+    z, out, loss, n_eval, grads = _oracle_run(tag)
+    assert n_eval == int(z["nonsat_evals"][1]) == int(z["nonsat_evals"][0])
+    assert H.rel_err(out, z["out64"]) <= 1e-9
+    assert abs(loss - float(z["loss64"])) <= 1e-10 * abs(float(z["loss64"]))
+    gmax = max(float(z[k][1]) for k in z.files if k.startswith("gstat."))
+    for k in z.files:
+        if k.startswith("gs64."):
+            name = k[len("gs64."):]
+            g = grads[name].reshape(-1)[H.sample_index(grads[name].size)]
+            mx = float(z["gstat." + name][1])
+            # (analytically zero gradients are rounding noise of 1e-16 in both double runs: absolute term)
+            assert float(np.abs(g - z[k]).max()) <= 1e-8 * mx + 1e-12 * gmax, name
+            assert abs(float(np.sqrt((grads[name] ** 2).sum())) - float(z["gstat." + name][0])) <= \
+                1e-8 * float(z["gstat." + name][0]) + 1e-12 * gmax, name
+
+
+def test_fixture_bounds_are_what_the_docstring_says():
+    """The numbers quoted above, asserted (so nobody reads the gradient bounds of the GPU test as hand-picked): outputs
+    of the reference's fp32 run within 1e-4 of its double run; median gradient distance between 1e-5 and 2e-2."""
+    for tag in H.FULL_TAGS:
+        z = H.load("full_" + tag)
+        assert 1e-6 <= H.rel_err(z["out32"], z["out64"]) <= 1e-4
+        gmax = max(float(z[k][1]) for k in z.files if k.startswith("gstat."))
+        rel = [float(z[k][2] / z[k][1]) for k in z.files if k.startswith("gstat.") and z[k][1] >= 1e-9 * gmax]
+        assert 1e-5 <= float(np.median(rel)) <= 2e-2, (tag, np.median(rel))
+
+
+@pytest.mark.parametrize("tag", ["below", "above"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_oracle_nonsat_decision_next_to_the_threshold(tag, dtype):
+    """Stop rule within 4e-7 of ep = 1e-4 (op_nonsat_margin.npz): the oracle takes the reference's evaluation count."""
+    from oracle import nn_ref as R
+    z = H.load("op_nonsat_margin")
+    n_atoms = [int(v) for v in z["n_atoms"]]
+    x = torch.from_numpy(z[tag + ".x"]).to(dtype).requires_grad_(True)
+    out, n_eval = R.nonsat(R.gather2d(x, n_atoms))
+    assert n_eval == int(z[tag + ".evals"])
+    assert abs(float(z[tag + ".means"][int(z["k_star"])]) - 1e-4) < 1e-6
+    assert H.rel_err(out.detach().numpy(), z[tag + ".out"]) <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["below", "above"])
+def test_hip_nonsat_decision_next_to_the_threshold(device, tag):
+    from jova_amd.nn import functional as F_
+    from jova_amd.nn.layers import GraphGather2D
+    z = H.load("op_nonsat_margin")
+    n_atoms = [int(v) for v in z["n_atoms"]]
+    x = torch.from_numpy(z[tag + ".x"]).to(device).requires_grad_(True)
+    out = GraphGather2D(activation="nonsat")([x, None, None, n_atoms], len(n_atoms))
+    ctrl = F_.NonsatFunction.last_n_eval.cpu().tolist()
+    assert ctrl[0] == int(z[tag + ".evals"]) and ctrl[2] == 0, "evaluations %s, reference %d" % (ctrl, int(z[tag + ".evals"]))
+    H.assert_close(out, z[tag + ".out"], tol=1e-5, what="out")
+    (out * torch.from_numpy(z[tag + ".gout"]).to(device)).sum().backward()
+    H.assert_close(x.grad, z[tag + ".gx"], tol=1e-5, what="dx")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", H.FULL_TAGS)
+def test_hip_step_vs_reference_full_size(device, tag):
+    from jova_amd.data.collate import collate_pairs
+    from jova_amd.feat.mol_graphs import ConvMol
+    from jova_amd.nn import functional as F_
+    from jova_amd.train import Trainer
+    z, spec, hparams, pool, mi, pi, y, w = H.full_setup(tag)
+    net = H.full_net(spec, hparams, pool)
+    H.check_full_weights(z, net)
+    net = net.to(device).train()
+    cms = [ConvMol(f, a, smiles=str(i)) for i, (f, a) in enumerate(pool.mols)]
+    batch = collate_pairs(pool, cms, mi, pi, y, w, device, net[0].models[2][0], with_psc="psc" in spec["views"])
+    tr = Trainer(net, hparams)
+    tr.flat.zero_grad()
+    loss, out = tr.forward_loss(batch)
+    loss.backward()
+    ctrl = F_.NonsatFunction.last_n_eval.cpu().tolist()
+    assert ctrl[0] == int(z["nonsat_evals"][0]) == int(z["nonsat_evals"][1]) and ctrl[2] == 0
+    e_ref = float(z["out_err32"])
+    e_out = H.rel_err(out.detach().cpu().numpy(), z["out64"])
+    assert e_out <= max(1e-5, 2 * e_ref), "outputs: err %.3e vs the reference's own fp32 %.3e" % (e_out, e_ref)
+    l64, l32 = float(z["loss64"]), float(z["loss32"])
+    assert abs(loss.item() - l64) <= max(1e-5, 2 * float(z["loss_err32"])) * abs(l64)
+    grads = {k: p.grad.detach().cpu().double().numpy() for k, p in net.named_parameters()}
+    emb = "0.models.2.0.embedding.weight"
+    assert float(np.abs(grads[emb][spec["hp"]["vocab"]]).max()) == 0.0         # the padding row receives nothing
+    H.check_full_grads(z, grads, tag)

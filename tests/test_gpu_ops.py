@@ -586,24 +586,65 @@ def test_overlapped_gradient_sync_on_rccl_single_rank(device):
         dist.destroy_process_group()
 
 
-def test_davis_full_size_step_vs_oracle(device):
-    """BASELINE.json config 2: the tuned Davis model, B = 128, fwd+bwd on the GPU against the fp64 oracle run on the host
-    with the same weights and the same batch (dropout off: its mask is RNG-specific).
+def _stage_grads(dtype, sd0, hp, pool, mi, pi, y, w, views_in=None, ja_in=None):
+    """Oracle (dtype) of the tuned model, stage by stage: graph / protein view encoders, joint attention, FC head.  Each
+    stage runs from GIVEN inputs when views_in / ja_in are handed in (the fp64 run's stage outputs), so stage errors do
+    not compound.  -> dict(views, ja, out, loss, d_views, d_ja, grads per parameter)."""
+    from oracle import mol_graphs as og
+    from oracle import nn_ref as R
+    b = og.agglomerate([og.SortedMol(*pool.mols[i]) for i in mi])
+    gl = og.gconv_input_list(b)
+    glist = [torch.from_numpy(gl[0]), torch.from_numpy(gl[1]), torch.from_numpy(gl[2]), gl[3]] + \
+            [torch.from_numpy(a) for a in gl[4:]]
+    idx = og.embedding_indices([pool.prot_names[i] for i in pi], pool.protein_profile, fill_val=pool.vocab)
+    p = {k: (v.to(dtype).requires_grad_("running" not in k) if v.is_floating_point() else v) for k, v in sd0.items()}
+    n_pcnn, n_lin = hp["prot"]["pcnn_num_layers"], len(hp["lin_dims"])
+    v_e = torch.from_numpy(pool.ecfp[mi]).to(dtype).unsqueeze(0)
+    v_g, _ = R.gconv_net(glist, p, prefix="0.models.1.0.")
+    v_p = R.pcnn2d(R.prot2vec(torch.from_numpy(idx), p["0.models.2.0.embedding.weight"]),
+                   [p["0.models.2.1.lin_kernels.%d.weight" % i] for i in range(n_pcnn)],
+                   [p["0.models.2.1.lin_kernels.%d.bias" % i] for i in range(n_pcnn)])
+    src = [v_e, v_g, v_p] if views_in is None else views_in
+    views = [t.detach().to(dtype).requires_grad_(True) for t in src]
+    ja = R.joint_attention(views, p, hp["attn_heads"], prefix="1.")
+    ja_leaf = (ja if ja_in is None else ja_in).detach().to(dtype).requires_grad_(True)
+    x, k = ja_leaf, 2
+    for _ in range(n_lin):
+        x = R.linear(x, p["%d.weight" % k], p["%d.bias" % k])
+        x = torch.relu(R.batch_norm_train(x, p["%d.weight" % (k + 1)], p["%d.bias" % (k + 1)]))
+        k += 4
+    out = R.linear(x, p["%d.weight" % k], p["%d.bias" % k])
+    loss = R.mse_loss(out, torch.from_numpy(w).to(dtype), torch.from_numpy(y).to(dtype))
+    return dict(p=p, glist=gl, v_g=v_g, v_p=v_p, views=views, ja=ja, ja_leaf=ja_leaf, out=out, loss=loss)
 
-    Forward, end to end: outputs within 3e-4 of scale, loss within 1e-5.
-    Backward, stage by stage (graph view, protein view, joint attention, FC head): each stage is run on the GPU from the
-    ORACLE's stage inputs and upstream gradient and every gradient is held to 1e-3 with the 5 % floor.  An end-to-end
-    element-wise gradient bound is not meaningful at this size in fp32: of the 81 536 pre-activations of the last
-    BatchNorm a handful lie within 1e-5 of zero, forward rounding of 1e-5 flips their ReLU masks (observed: 2 flips for
-    this seed; an fp32 run of the oracle flips others), and one flipped sample moves a weight-gradient row by ~1/sqrt(B).
-    So end to end the gradient is bounded in the L2 norm over all parameters (2e-2) instead."""
+
+def _stage_backward(st, d_ja=None, d_views=None):
+    """Backward of _stage_grads' stages, each from a GIVEN upstream gradient when one is handed in."""
+    st["loss"].backward()
+    st["ja"].backward(st["ja_leaf"].grad if d_ja is None else d_ja.to(st["ja"].dtype))
+    dv = [v.grad for v in st["views"]] if d_views is None else [t.to(st["v_g"].dtype) for t in d_views]
+    st["v_g"].backward(dv[1])
+    st["v_p"].backward(dv[2])
+    return {k: v.grad.detach().double() for k, v in st["p"].items()
+            if torch.is_tensor(v) and v.requires_grad and v.grad is not None}
+
+
+def test_davis_full_size_stages_vs_oracle(device):
+    """BASELINE.json config 2, stage by stage: the tuned Davis model, B = 128, every stage (graph view, protein view,
+    joint attention, FC head) run on the GPU from the fp64 ORACLE's stage inputs and upstream gradients, so that ReLU
+    mask flips of one stage do not leak into the next.  (End to end, against the imported reference, with bounds from
+    the reference's own fp32 run: tests/test_full_size_parity.py.)
+
+    Bounds are derived, not picked: the fp32 oracle (torch CPU arithmetic, as the reference's fp32 run) goes through
+    the same stages from the same fp64 inputs, and every HIP tensor is held to
+        err(hip, oracle64) <= max(1e-5, 2 * err(oracle32, oracle64))          err = max|a - b| / max|oracle64|,
+    with err(oracle32, oracle64) of a parameter gradient taken no smaller than its stage's whole-gradient L2 distance.
+    Gradients that are analytically zero (< 1e-9 of the largest) are judged on 1e-5 of the largest gradient."""
     from jova_amd import synth
     from jova_amd.data.collate import collate_pairs
     from jova_amd.feat.mol_graphs import ConvMol
     from jova_amd.nn import functional as F_
     from jova_amd.train import TUNED_DAVIS_HPARAMS, Trainer, create_integrated_net
-    from oracle import mol_graphs as og
-    from oracle import nn_ref as R
     hp = dict(TUNED_DAVIS_HPARAMS)
     hp["dprob"] = 0.0
     pool = synth.SyntheticPool("davis", seed=8)
@@ -616,155 +657,69 @@ def test_davis_full_size_step_vs_oracle(device):
     mi, pi, y, w = pool.sample_pairs(np.random.RandomState(64), 128)
     batch = collate_pairs(pool, cms, mi, pi, y, w, device, net[0].models[2][0])
     tr = Trainer(net, hp)
-    tr.flat.zero_grad()
-    loss, out = tr.forward_loss(batch)
-    loss.backward()
-    e2e_grad = {k: v.grad.detach().cpu().double() for k, v in named.items()}
 
-    # ---- oracle on the host, stage by stage, fp64
     torch.set_num_threads(8)
-    b = og.agglomerate([og.SortedMol(*pool.mols[i]) for i in mi])
-    gl = og.gconv_input_list(b)
-    for got, want in zip(batch.glist, gl):                      # index tensors bit-exact at full size
+    s64 = _stage_grads(torch.float64, sd0, hp, pool, mi, pi, y, w)
+    g64 = _stage_backward(s64)
+    d_ja64 = s64["ja_leaf"].grad.detach()
+    d_views64 = [v.grad.detach() for v in s64["views"]]
+    s32 = _stage_grads(torch.float32, sd0, hp, pool, mi, pi, y, w, views_in=s64["views"], ja_in=s64["ja"])
+    g32 = _stage_backward(s32, d_ja=d_ja64, d_views=d_views64)
+    for got, want in zip(batch.glist, s64["glist"]):            # index tensors bit-exact at full size
         if isinstance(want, np.ndarray):
             assert np.array_equal(got.cpu().numpy(), want)
-    glist = [torch.from_numpy(gl[0]), torch.from_numpy(gl[1]), torch.from_numpy(gl[2]), gl[3]] + \
-            [torch.from_numpy(a) for a in gl[4:]]
-    idx = og.embedding_indices([pool.prot_names[i] for i in pi], pool.protein_profile, fill_val=pool.vocab)
-    p = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v) for k, v in sd0.items()}
-    n_pcnn, n_lin = hp["prot"]["pcnn_num_layers"], len(hp["lin_dims"])
-    v_e = torch.from_numpy(pool.ecfp[mi]).double().unsqueeze(0)
-    v_g, _ = R.gconv_net(glist, p, prefix="0.models.1.0.")
-    v_p = R.pcnn2d(R.prot2vec(torch.from_numpy(idx), p["0.models.2.0.embedding.weight"]),
-                   [p["0.models.2.1.lin_kernels.%d.weight" % i] for i in range(n_pcnn)],
-                   [p["0.models.2.1.lin_kernels.%d.bias" % i] for i in range(n_pcnn)])
-    views = [v_e.requires_grad_(True), v_g.detach().requires_grad_(True), v_p.detach().requires_grad_(True)]
-    ja = R.joint_attention(views, p, hp["attn_heads"], prefix="1.")
-    ja_in = ja.detach().requires_grad_(True)
-    x, k = ja_in, 2
-    for _ in range(n_lin):
-        x = R.linear(x, p["%d.weight" % k], p["%d.bias" % k])
-        x = torch.relu(R.batch_norm_train(x, p["%d.weight" % (k + 1)], p["%d.bias" % (k + 1)]))
-        k += 4
-    want = R.linear(x, p["%d.weight" % k], p["%d.bias" % k])
-    wl = R.mse_loss(want, torch.from_numpy(w), torch.from_numpy(y))
-    wl.backward()                                               # head parameters + d loss / d ja
-    ja.backward(ja_in.grad)                                     # joint-attention parameters + d loss / d views
-    v_g.backward(views[1].grad)                                 # graph view parameters
-    v_p.backward(views[2].grad)                                 # protein view parameters
-    want_grad = {}
-    for k, v in p.items():
-        if torch.is_tensor(v) and v.requires_grad and v.grad is not None:
-            g = v.grad.clone()
-            if k.endswith("embedding.weight"):
-                g[hp["prot"]["vocab_size"]] = 0                 # the padding row is never updated
-            want_grad[k] = g
-    gmax = max(float(g.abs().max()) for g in want_grad.values())
+    vocab = hp["prot"]["vocab_size"]
+    for g in (g64, g32):
+        g["0.models.2.0.embedding.weight"][vocab] = 0            # the padding row is never updated
+    gmax = max(float(g.abs().max()) for g in g64.values())
 
-    # ---- forward, end to end
-    H.assert_close(out, want.detach(), tol=3e-4, what="outputs")
-    assert abs(loss.item() - float(wl.detach())) <= 1e-5 * abs(float(wl.detach()))
-
-    # ---- backward, end to end, L2 over all parameters
-    num = sum(float(((e2e_grad[k] - g) ** 2).sum()) for k, g in want_grad.items())
-    den = sum(float((g ** 2).sum()) for g in want_grad.values())
-    assert (num / den) ** 0.5 <= 2e-2, "end-to-end gradient L2 error %.3e" % ((num / den) ** 0.5)
-
-    # ---- backward, stage by stage, from the oracle's inputs
     def f32(t):
         return t.detach().float().to(device)
 
+    def held(got, ref32, ref64, what, floor=0.0):
+        e_ref = H.rel_err(ref32.detach().double().numpy(), ref64.detach().double().numpy())
+        e = H.rel_err(got.detach().cpu().double().numpy(), ref64.detach().double().numpy())
+        bound = max(1e-5, 2 * max(e_ref, floor))
+        assert e <= bound, "%s: err %.3e > %.3e (fp32 oracle: %.3e)" % (what, e, bound, e_ref)
+
     def check(prefixes):
-        seen = 0
-        for k, g in want_grad.items():
-            if any(k.startswith(q) for q in prefixes):
-                H.assert_close(named[k].grad, g, tol=1e-3, what=k, floor=0.05 * gmax)
-                seen += 1
-        assert seen > 0
+        keys = [k for k in g64 if any(k.startswith(q) for q in prefixes)]
+        assert keys
+        e_stage = (sum(float(((g32[k] - g64[k]) ** 2).sum()) for k in keys) /
+                   sum(float((g64[k] ** 2).sum()) for k in keys)) ** 0.5
+        for k in keys:
+            if float(g64[k].abs().max()) < 1e-9 * gmax:
+                assert float(named[k].grad.abs().max()) <= 1e-5 * gmax, k
+            else:
+                held(named[k].grad, g32[k], g64[k], k, floor=e_stage)
 
     # FC head
     tr.flat.zero_grad()
-    xg = f32(ja).requires_grad_(True)
+    xg = f32(s64["ja"]).requires_grad_(True)
     h = xg
     for i in range(2, len(net)):
         h = net[i](h)
     F_.MSELossFunction.apply(h, batch.w, batch.y).backward()
-    H.assert_close(xg.grad, ja_in.grad, tol=1e-4, what="d loss / d joint-attention output")
+    held(h, s32["out"], s64["out"], "outputs from the oracle's joint-attention output")
+    held(xg.grad, s32["ja_leaf"].grad, d_ja64, "d loss / d joint-attention output")
     check(["%d." % i for i in range(2, len(net))])
     # joint attention
     tr.flat.zero_grad()
-    vg = [f32(v).requires_grad_(True) for v in views]
-    net[1](vg).backward(f32(ja_in.grad))
+    vg = [f32(v).requires_grad_(True) for v in s64["views"]]
+    ja_hip = net[1](vg)
+    held(ja_hip, s32["ja"], s64["ja"], "joint-attention output")
+    ja_hip.backward(f32(d_ja64))
     for i in range(3):
-        H.assert_close(vg[i].grad, views[i].grad, tol=2e-3, what="d loss / d view %d" % i)
+        held(vg[i].grad, s32["views"][i].grad, d_views64[i], "d loss / d view %d" % i)
     check(["1."])
     # graph view and protein view
     tr.flat.zero_grad()
     got_views = net[0](batch.model_input())
-    H.assert_close(got_views[1], v_g.detach(), tol=1e-5, what="graph view")
-    H.assert_close(got_views[2], v_p.detach(), tol=1e-5, what="protein view")
-    got_views[1].backward(f32(views[1].grad))
-    got_views[2].backward(f32(views[2].grad))
+    H.assert_close(got_views[1], s64["v_g"].detach(), tol=1e-5, what="graph view")
+    H.assert_close(got_views[2], s64["v_p"].detach(), tol=1e-5, what="protein view")
+    got_views[1].backward(f32(d_views64[1]))
+    got_views[2].backward(f32(d_views64[2]))
     check(["0."])
-
-
-@pytest.mark.parametrize("shape,views", [("kiba", ("pcnn2d",)), ("metz", ("pcnn2d", "psc"))])
-def test_kiba_and_metz_shaped_step_vs_oracle(device, shape, views):
-    """BASELINE.json configs 3 and 5 at full per-GPU size: KIBA-shaped pairs (drugs to 70 atoms, proteins to 376
-    segments: S up to 447 tokens) and Metz-shaped pairs with the fourth view ``psc`` ([B,8421] descriptors,
-    ecfp8-gconv__pcnn2d-psc), B = 128, tuned model, dropout off.  Index tensors bit-exact; outputs and loss against the
-    fp64 oracle with the same weights; the gradient in the L2 norm over all parameters (why not element-wise: see the
-    Davis test above), plus the embedding gradient's padding row."""
-    from jova_amd import synth
-    from jova_amd.data.collate import collate_pairs
-    from jova_amd.feat.mol_graphs import ConvMol
-    from jova_amd.train import TUNED_DAVIS_HPARAMS, Trainer, create_integrated_net
-    from oracle import mol_graphs as og
-    from oracle import nn_ref as R
-    hp = dict(TUNED_DAVIS_HPARAMS)
-    hp["dprob"] = 0.0
-    hp["prot"] = dict(hp["prot"], model_types=list(views))
-    pool = synth.SyntheticPool(shape, seed=1, n_mols=160, n_prots=96)
-    cms = [ConvMol(f, a, smiles=str(i)) for i, (f, a) in enumerate(pool.mols)]
-    torch.manual_seed(64)
-    net = create_integrated_net(hp, pool.protein_profile)
-    sd0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    net = net.to(device).train()
-    named = dict(net.named_parameters())
-    mi, pi, y, w = pool.sample_pairs(np.random.RandomState(8), 128)
-    batch = collate_pairs(pool, cms, mi, pi, y, w, device, net[0].models[2][0], with_psc="psc" in views)
-    tr = Trainer(net, hp)
-    tr.flat.zero_grad()
-    loss, out = tr.forward_loss(batch)
-    loss.backward()
-
-    torch.set_num_threads(8)
-    b = og.agglomerate([og.SortedMol(*pool.mols[i]) for i in mi])
-    gl = og.gconv_input_list(b)
-    for got, want in zip(batch.glist, gl):
-        if isinstance(want, np.ndarray):
-            assert np.array_equal(got.cpu().numpy(), want)
-    glist = [torch.from_numpy(gl[0]), torch.from_numpy(gl[1]), torch.from_numpy(gl[2]), gl[3]] + \
-            [torch.from_numpy(a) for a in gl[4:]]
-    idx = og.embedding_indices([pool.prot_names[i] for i in pi], pool.protein_profile, fill_val=pool.vocab)
-    p = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v) for k, v in sd0.items()}
-    ob = dict(ecfp=torch.from_numpy(pool.ecfp[mi]).double(), glist=glist, prot_idx=torch.from_numpy(idx),
-              psc=torch.from_numpy(pool.psc[pi]).double() if "psc" in views else None)
-    want, _ = R.dti_forward(p, ob, hp["attn_heads"], hp["prot"]["pcnn_num_layers"], len(hp["lin_dims"]))
-    wl = R.mse_loss(want, torch.from_numpy(w), torch.from_numpy(y))
-    wl.backward()
-    H.assert_close(out, want.detach(), tol=3e-4, what="outputs")
-    assert abs(loss.item() - float(wl.detach())) <= 1e-5 * abs(float(wl.detach()))
-    num = den = 0.0
-    for k, v in p.items():
-        if torch.is_tensor(v) and v.requires_grad and v.grad is not None:
-            g = v.grad.clone()
-            if k.endswith("embedding.weight"):
-                g[hp["prot"]["vocab_size"]] = 0
-                assert float(named[k].grad[hp["prot"]["vocab_size"]].abs().max()) == 0.0
-            num += float(((named[k].grad.detach().cpu().double() - g) ** 2).sum())
-            den += float((g ** 2).sum())
-    assert (num / den) ** 0.5 <= 2e-2, "end-to-end gradient L2 error %.3e" % ((num / den) ** 0.5)
 
 
 def test_config4_graph_stack_vs_oracle(device):
@@ -832,5 +787,52 @@ def test_config4_graph_stack_vs_oracle(device):
     assert torch.equal(dx_g, dx_r), "pool backward: precomputed reverse positions change the result"
     assert int((topo.rev_pos == 0xFF).sum()) == 0, "symmetric graph: every edge has its reverse"
     H.assert_close(dx_g.double().sum(0), dy.double().sum(0), tol=1e-6, what="pool backward conserves column sums")
-    o3.sum().backward()
-    assert torch.isfinite(x3.grad).all()
+    # ---- backward at full size against the fp64 oracle (autograd of oracle/nn_ref.py), bounds derived from the fp32
+    # oracle on the same inputs: err(hip, o64) <= max(1e-5, 2 * err(o32, o64)) per tensor
+    g3 = torch.randn(o3.shape, generator=torch.Generator().manual_seed(4))
+    g1 = torch.randn(o1.shape, generator=torch.Generator().manual_seed(5))
+    for q in list(c1.parameters()) + list(c2.parameters()):
+        q.grad = None
+    (o3 * g3.to(device)).sum().backward()
+    (o1 * g1.to(device)).sum().backward()
+
+    def oracle_bwd(dtype):
+        x = o2.detach().cpu().to(dtype).requires_grad_(True)
+        W2 = [t.to(dtype).requires_grad_(True) for t in w2]
+        B2 = [t.to(dtype).requires_grad_(True) for t in b2]
+        W1 = [t.to(dtype).requires_grad_(True) for t in w1]
+        B1 = [t.to(dtype).requires_grad_(True) for t in b1]
+        (R.graph_pool(R.graph_conv(x, cpu_l[1], cpu_l[4:], W2, B2), cpu_l[1], cpu_l[4:]) * g3.to(dtype)).sum().backward()
+        (R.graph_conv(cpu_l[0], cpu_l[1], cpu_l[4:], W1, B1) * g1.to(dtype)).sum().backward()
+        return dict(x=x.grad, w2=[t.grad for t in W2], b2=[t.grad for t in B2], w1=[t.grad for t in W1],
+                    b1=[t.grad for t in B1])
+    r64, r32 = oracle_bwd(torch.float64), oracle_bwd(torch.float32)
+
+    def held(got, a32, a64, what):
+        e_ref = H.rel_err(a32.double().numpy(), a64.numpy())
+        e = H.rel_err(got.detach().cpu().double().numpy(), a64.numpy())
+        assert e <= max(1e-5, 2 * e_ref), "%s: err %.3e, fp32 oracle %.3e" % (what, e, e_ref)
+    held(x3.grad, r32["x"], r64["x"], "config 4: conv2+pool dX")
+    for k in range(21):
+        held(c2.linear_layers[k].weight.grad, r32["w2"][k], r64["w2"][k], "config 4: conv2 dW[%d]" % k)
+        held(c2.linear_layers[k].bias.grad, r32["b2"][k], r64["b2"][k], "config 4: conv2 db[%d]" % k)
+        held(c1.linear_layers[k].weight.grad, r32["w1"][k], r64["w1"][k], "config 4: conv1 dW[%d]" % k)
+        held(c1.linear_layers[k].bias.grad, r32["b1"][k], r64["b1"][k], "config 4: conv1 db[%d]" % k)
+    # pool backward alone, element-wise against autograd of the oracle's pool (exact routing: 1e-6)
+    xo = o1.detach().cpu().double().requires_grad_(True)
+    (R.graph_pool(xo, cpu_l[1], cpu_l[4:]) * dy.cpu().double()).sum().backward()
+    H.assert_close(dx_r, xo.grad, tol=1e-6, what="config 4: pool backward vs oracle")
+    # gather2d + nonsat at this size (g = 128): forward, evaluation count and backward
+    from jova_amd.nn.layers import GraphGather2D
+    xg = torch.randn(o1.shape[0], 128, generator=torch.Generator().manual_seed(6))
+    gg = None
+    xd = xg.to(device).requires_grad_(True)
+    og_ = GraphGather2D(activation="nonsat")([xd] + glist[1:], len(glist[3]))
+    gg = torch.randn(og_.shape, generator=torch.Generator().manual_seed(7))
+    (og_ * gg.to(device)).sum().backward()
+    xc = xg.double().requires_grad_(True)
+    want, n_eval = R.nonsat(R.gather2d(xc, glist[3]))
+    (want * gg.double()).sum().backward()
+    assert F_.NonsatFunction.last_n_eval.cpu().tolist()[0] == n_eval
+    H.assert_close(og_, want.detach(), tol=1e-5, what="config 4: gather2d + nonsat")
+    H.assert_close(xd.grad, xc.grad, tol=1e-5, what="config 4: gather2d + nonsat backward")
