@@ -202,10 +202,10 @@ def graph_stress(device, reps=20, full=True, row_order_lines=True):
     # per-step kernel reads 4-byte features: algorithmic bytes as SURVEY.md section 8d
     timed("graphconv_fwd_l1(75->64)", lambda: call("jova_graphconv_fwd", P(x1), 0, x1.shape[1], n, 75, 64, ds, adj, pw1,
                                                    pb1, 1, P(out), None, P(ws1), dsh, st),
-          4 * (n * 75 + n * 64 + e) + 4 * 21 * 76 * 64, launches=2, kernels=("graphconv_fwd_dma_kernel<10, 4>",))
+          4 * (n * 75 + n * 64 + e) + 4 * 21 * 76 * 64, launches=1, kernels=("graphconv_fwd_wave_kernel<10, 3, false>",))
     timed("graphconv_fwd_l2(64->64)", lambda: call("jova_graphconv_fwd", P(x2), 0, 64, n, 64, 64, ds, adj, pw2, pb2, 1,
                                                    P(out), None, P(ws2), dsh, st),
-          4 * (n * 64 + n * 64 + e) + wbytes, launches=2, kernels=("graphconv_fwd_dma_kernel<8, 4>",))
+          4 * (n * 64 + n * 64 + e) + wbytes, launches=1, kernels=("graphconv_fwd_wave_kernel<8, 4, false>",))
     order = P(topo.block_order)
     timed("graphpool_fwd(64)", lambda: call("jova_graphpool_fwd", P(x2), n, 64, ds, adj, P(out), P(arg), order, st),
           4 * (2 * n * 64 + e) + n * 64, kernels=("graphpool_fwd_v4_kernel",))

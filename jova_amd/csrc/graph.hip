@@ -1805,6 +1805,428 @@ __global__ void mul_kernel(const float* __restrict__ a, const float* __restrict_
         out[e] = a[e] * b[e];
 }
 
+// ------------------------------------------------------------------------------------------------ forward, wave-private form
+// Second-generation forward (fp32 rows of 64 or 80 floats, f_out = 64): no workgroup barrier in the loop at all.
+//   * a WAVE owns 16-atom tiles (v_mfma_f32_16x16x4_f32: 16 atoms x 16 output features per instruction, 32 cycles,
+//     four independent accumulators = the 64 output features), eight waves per workgroup, one workgroup per CU, all of
+//     one degree bucket; the bucket's two weight matrices sit in LDS once per workgroup (fragment order, one
+//     conflict-free ds_read_b128 per four MFMAs), so a wave needs ~150 registers and two waves share a SIMD: while one
+//     waits for its rows the other owns the matrix pipe.
+//   * rows travel HBM/L2 -> the wave's own LDS planes by global_load_lds_dwordx4 (inline asm: completion is tracked by
+//     hand with s_waitcnt vmcnt(N), nothing else in the workgroup is involved), chunk c of row r at position c ^ r, and
+//     are read back as MFMA fragments straight into registers (own rows X, neighbour sum S formed while reading).
+//     Once a tile's fragments are in registers its planes are free: the DMA of the wave's NEXT tile, the index loads of
+//     the tile after that and the four stores of the PREVIOUS tile are issued one by one between the groups of MFMAs of
+//     the current tile (128 MFMAs = 4 096 cycles), so the vector-memory issue stalls (100-200 cycles per instruction,
+//     measured) sit in the shadow of the matrix pipe instead of in front of it.
+//   * out^T = W x^T: the weights are the A operand and the atoms the B operand, so a lane ends up with four CONSECUTIVE
+//     output features of one atom: one 16-byte store per accumulator, 64 contiguous bytes per atom and instruction.
+//   * k order permuted as in the 32-atom form: MFMA step (m, s) contracts features 16 m + 4 q + s (q = lane >> 4).
+//   * work split on the host (WavePlan): workgroups per bucket in proportion to its cost, at most one workgroup per CU;
+//     inside a bucket workgroup b takes the chunk whose relative position matches its XCD (b % 8), so the neighbour rows
+//     (same molecule, about the same relative position in their own buckets) are fetched into ONE L2.
+#define WT 16
+struct WavePlan {
+    int first[NB + 1];       // workgroups [first[k], first[k + 1]) work on bucket of degree 10 - k
+    int start[NB];           // by degree
+    int size[NB];
+};
+
+__device__ __forceinline__ void dma16_m0(const float* g, unsigned lds) {        // lds: wave-uniform LDS byte address
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_byte_addr(const float* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) float*)p);
+}
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// The 16 NM (x 2 with neighbours) MFMAs of one 16-atom tile.  Weight fragments of step m + 1 are read from LDS while
+// the MFMAs of step m run; every accumulator is reused after four independent MFMAs (40-cycle latency).  `side(k)` is
+// called in front of every group of 4 (8) MFMAs, k = 0 .. 4 NM - 1: the wave's memory traffic for its OTHER tiles (DMA
+// of the next tile's rows, stores of the previous tile's results) is issued there, in the shadow of the matrix pipe.
+template <int NM, bool REL, typename Side>
+__device__ __forceinline__ void wave_mfma_tile(const float* wl0, const float* wl1, const f32x4v (&xf)[NM],
+                                               const f32x4v (&sf)[NM], f32x4v (&acc)[4], Side&& side) {
+    f32x4v ws[2][4], wr[2][4];
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+        ws[0][fb] = *reinterpret_cast<const f32x4v*>(wl0 + (fb * NM) * 256);
+        if (REL) wr[0][fb] = *reinterpret_cast<const f32x4v*>(wl1 + (fb * NM) * 256);
+    }
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const int c = m & 1, nx = c ^ 1;
+        if (m + 1 < NM) {
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb) {
+                ws[nx][fb] = *reinterpret_cast<const f32x4v*>(wl0 + (fb * NM + m + 1) * 256);
+                if (REL) wr[nx][fb] = *reinterpret_cast<const f32x4v*>(wl1 + (fb * NM + m + 1) * 256);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);           // reads of step m + 1 are issued in front of the MFMAs of step m
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            side(4 * m + s);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb)
+                acc[fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[c][fb][s], xf[m][s], acc[fb], 0, 0, 0);
+            if (REL) {
+#pragma unroll
+                for (int fb = 0; fb < 4; ++fb)
+                    acc[fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[c][fb][s], sf[m][s], acc[fb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+#ifndef JOVA_WAVE_STAGGER
+#define JOVA_WAVE_STAGGER 64          // x 64 cycles
+#endif
+#ifdef JOVA_WAVE_PROFILE
+__device__ unsigned long long g_wave_prof[256 * 8 * 8 + 512];
+extern "C" int jova_debug_wave_prof(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wave_prof), sizeof(unsigned long long) * n);
+}
+#define WPROF(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define WPROF(var)
+#endif
+
+template <int KG, int NPL, bool STATS>
+__global__ void __launch_bounds__(512, 1)
+graphconv_fwd_wave_kernel(const float* __restrict__ x, int n_atoms, int ldx, int f_in, GcParams P, int relu, float* __restrict__ out, double* __restrict__ stats, WavePlan plan) {
+    constexpr int NM = KG / 2;                       // b128 fragment reads per row: 16 features each
+    constexpr int NS = 4 * NM;                       // side slots of a tile's MFMA phase
+    constexpr int NBR = NPL - 1;                     // neighbour planes per gather round
+    constexpr int PPP = KG > 8 ? 5 : 4;              // DMA pieces (1 KiB wave-instructions) per plane
+    constexpr int TAIL_F = KG > 8 ? WT * 16 : 0;
+    constexpr int PLANE_F = WT * 64 + TAIL_F;        // floats per plane: [16 rows][64] main image (+ [16][16] tail image)
+    constexpr int WMAT_F = 4 * NM * 256;             // floats per weight matrix image
+    static_assert(NPL * PPP <= NS, "every DMA piece of a tile needs a side slot");
+    __shared__ __attribute__((aligned(16))) float lds[2 * WMAT_F + 8 * NPL * PLANE_F];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 15, q = lane >> 4;
+#ifdef JOVA_WAVE_PROFILE
+    const unsigned long long pf_entry = __builtin_readcyclecounter();
+    const unsigned long long pf_wall0 = wall_clock64();
+#endif
+
+    // ---- this workgroup's bucket and its chunk of the bucket's tiles
+    int kb = 0;
+#pragma unroll
+    for (int k = 1; k < NB; ++k) kb += ((int)blockIdx.x >= plan.first[k]) ? 1 : 0;
+    const int deg = NB - 1 - kb;
+    const int wg0 = plan.first[kb], nwg = plan.first[kb + 1] - wg0;
+    int bstart = 0, bsize = 0;
+#pragma unroll
+    for (int d = 0; d < NB; ++d) {
+        if (d == deg) { bstart = plan.start[d]; bsize = plan.size[d]; }
+    }
+    int chunk = 0;
+    {
+        const int xcd = blockIdx.x & 7, j = (int)blockIdx.x - wg0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j0 = (k - wg0) & 7;
+            const int cnt = j0 < nwg ? (nwg - j0 + 7) >> 3 : 0;
+            chunk += k < xcd ? cnt : 0;
+        }
+        chunk += (j - ((xcd - wg0) & 7)) >> 3;
+    }
+    const int tiles = (bsize + WT - 1) / WT;
+    const int per = (tiles + nwg - 1) / nwg;
+    const int t_begin = chunk * per, t_end = min(tiles, t_begin + per);
+    // tiles of this wave: t_begin + wave + 8 n  (claiming them from a per-workgroup counter was measured: the atomic's
+    // round trip costs more than the <= 1 tile of imbalance it removes)
+    const int t0 = t_begin + wave;
+
+    float* const pl = lds + 2 * WMAT_F + wave * (NPL * PLANE_F);
+    const unsigned pl_addr = lds_byte_addr(pl);
+    const int* adj_d = deg > 0 ? P.adj[deg - 1] : nullptr;
+    const unsigned nmax = (unsigned)(n_atoms - 1);
+    const int swzt = ((4 - (i >> 2)) & 3);           // tail image swizzle by row group: 0, 3, 2, 1
+    const int cnt0 = min(deg, NBR);                  // neighbour planes of a tile's first gather round
+
+    // neighbour row numbers of a gather round, in the DMA's lane -> row map (main image: lane L covers row 4 j + (L >> 4)
+    // with piece j; tail image: row L >> 2).  Only the planes the round uses are loaded.
+    int ix[NBR][4];
+    int ixt[KG > 8 ? NBR : 1];
+    auto load_idx = [&](int t, int nb0) {
+        const int lrow0 = t * WT, rows = min(WT, bsize - lrow0);
+#pragma unroll
+        for (int p = 0; p < NBR; ++p) {
+            if (nb0 + p < deg) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = min(4 * j + q, rows - 1);
+                    ix[p][j] = adj_d[(lrow0 + r) * deg + nb0 + p];
+                }
+                if (KG > 8) {
+                    const int r = min(lane >> 2, rows - 1);
+                    ixt[p] = adj_d[(lrow0 + r) * deg + nb0 + p];
+                }
+            }
+        }
+    };
+    // DMA piece j of a plane (j < 4: rows 4 j .. 4 j + 3 of the main image, j == 4: the tail image)
+    auto issue_piece = [&](int pp, int j, int row) {
+        if (j < 4) {
+            const unsigned r = 4 * j + q;
+            const float* g = x + ((size_t)min((unsigned)row, nmax) * (unsigned)ldx + (((lane & 15) ^ r) << 2));
+            dma16_m0(g, pl_addr + (pp * PLANE_F + j * 256) * 4);
+        } else {
+            const int sw = (4 - (lane >> 4)) & 3;                     // row group of row (lane >> 2)
+            const float* g = x + ((size_t)min((unsigned)row, nmax) * (unsigned)ldx + 64 + (((lane & 3) ^ sw) << 2));
+            dma16_m0(g, pl_addr + (pp * PLANE_F + WT * 64) * 4);
+        }
+    };
+    // piece k (= plane k / PPP, piece k % PPP) of the first gather round of tile t, if that round has such a plane
+    auto issue_round0_piece = [&](int t, int k) {
+        const int pp = k / PPP, j = k % PPP;
+        if (pp > cnt0) return;
+        const int lrow0 = t * WT, rows = min(WT, bsize - lrow0);
+        int row;
+        if (pp == 0) row = bstart + lrow0 + min(j < 4 ? 4 * j + q : lane >> 2, rows - 1);
+        else row = j < 4 ? ix[pp - 1 < NBR ? pp - 1 : 0][j < 4 ? j : 0] : ixt[KG > 8 ? (pp - 1 < NBR ? pp - 1 : 0) : 0];
+        issue_piece(pp, j, row);
+    };
+    // fragments of plane pp: NM float4 per lane (row i; read m = features 16 m + 4 q .. + 3)
+    auto read_plane = [&](int pp, f32x4v (&f)[NM]) {
+        const float* b = pl + pp * PLANE_F;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            if (m < 4) f[m] = *reinterpret_cast<const f32x4v*>(b + i * 64 + (((4 * m + q) ^ i) << 2));
+            else f[m] = *reinterpret_cast<const f32x4v*>(b + WT * 64 + i * 16 + ((q ^ swzt) << 2));
+        }
+    };
+
+    // ---- prologue: the first tile's indices are requested first, the bucket's weights (slot 0: W_self, slot 1: W_rel)
+    // go to LDS while they travel, then the first tile's rows are requested: two memory round trips, not five
+    int tc = t0, tn = t0 + 8, tn2 = 0;               // current tile, next (rows in flight), the one after (indices)
+    if (tc < t_end && deg > 0) load_idx(tc, 0);
+
+    const int w_rel = deg > 0 ? 2 * (deg - 1) : 20, w_self = deg == 0 ? 20 : 2 * (deg - 1) + 1;
+    {
+        // weights straight from the layer's [64][f_in] matrices into fragment order (no separate re-pack launch):
+        //   image[mat][fb][m][lane][s] = W[16 fb + (lane & 15)][16 m + 4 (lane >> 4) + s], zero beyond f_in
+        const float* W0 = P.w[w_self];
+        const float* W1 = P.w[w_rel];
+        constexpr int NE = (WMAT_F / 4 + 511) / 512;
+        const bool vec = (f_in & 3) == 0;
+        float4 a[NE], b[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int o = min(tid + 512 * e, WMAT_F / 4 - 1);
+            const int ln = o & 63, fm = o >> 6;                  // fm = fb * NM + m
+            const int row = 16 * (fm / NM) + (ln & 15), k = 16 * (fm % NM) + 4 * (ln >> 4);
+            if (vec) {
+                const bool ok = k < f_in;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                a[e] = ok ? *reinterpret_cast<const float4*>(W0 + row * f_in + k) : z;
+                b[e] = ok ? *reinterpret_cast<const float4*>(W1 + row * f_in + k) : z;
+            } else {
+                float va[4], vb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = min(k + u, f_in - 1);
+                    va[u] = W0[row * f_in + kk];
+                    vb[u] = W1[row * f_in + kk];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (k + u >= f_in) va[u] = vb[u] = 0.f;
+                }
+                a[e] = make_float4(va[0], va[1], va[2], va[3]);
+                b[e] = make_float4(vb[0], vb[1], vb[2], vb[3]);
+            }
+        }
+        float4* d0 = reinterpret_cast<float4*>(lds);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int o = min(tid + 512 * e, WMAT_F / 4 - 1);        // (the clamped duplicates rewrite the same values)
+            d0[o] = a[e];
+            d0[WMAT_F / 4 + o] = b[e];
+        }
+    }
+    f32x4v bias[4];
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = 16 * fb + 4 * q + r;
+            bias[fb][r] = P.b[w_self][col] + (deg > 0 ? P.b[w_rel][col] : 0.f);
+        }
+    }
+    if (tc < t_end) {
+#pragma unroll
+        for (int k = 0; k < NPL * PPP; ++k) issue_round0_piece(tc, k);
+        if (deg > 0 && tn < t_end) load_idx(tn, 0);
+    }
+    __syncthreads();                                 // the weights are in LDS: the only barrier in front of the loop
+    tn2 = tn + 8;
+    // The two waves of a SIMD (w and w + 4) run the same program; started together they stay in lockstep and meet the
+    // matrix pipe, the LDS reads and the stores together.  Half a tile of delay for waves 4..7 puts one wave's
+    // read / epilogue phases beside the other's MFMA phase (MI355X_MICROARCH.md, "try a stagger").
+    if (wave >= 4 && JOVA_WAVE_STAGGER > 0) __builtin_amdgcn_s_sleep(JOVA_WAVE_STAGGER);
+
+    float ssum[4][4], ssq[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) ssum[a][b] = ssq[a][b] = 0.f;
+    const float* wl0 = lds + lane * 4;
+    const float* wl1 = lds + WMAT_F + lane * 4;
+    f32x4v prev[4];                                  // results of the previous tile, stored during this tile's MFMA phase
+    float* prev_row = nullptr;
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) prev[fb] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#ifdef JOVA_WAVE_PROFILE
+    unsigned long long pf_wait = 0, pf_read = 0, pf_mfma = 0, pf_epi = 0;
+    const unsigned long long pf_start = __builtin_readcyclecounter();
+#endif
+    int n_done = 0;
+    for (; tc < t_end; tc = tn, tn = tn2, tn2 += 8, ++n_done) {
+        const int t = tc;
+        const int lrow0 = t * WT, rows = min(WT, bsize - lrow0);
+        WPROF(p0);
+        // this tile's rows landed: they were requested during the previous tile's MFMA phase
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::: "memory");
+        WPROF(p1);
+        f32x4v xf[NM], sf[NM];
+        read_plane(0, xf);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) sf[m] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < NBR; ++p) {
+            if (p < deg) {
+                f32x4v f[NM];
+                read_plane(1 + p, f);
+#pragma unroll
+                for (int m = 0; m < NM; ++m) sf[m] += f[m];
+            }
+        }
+        for (int nb0 = NBR; nb0 < deg; nb0 += NBR) {               // further gather rounds of a high-degree tile
+            load_idx(t, nb0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the planes' previous contents have been read
+#pragma unroll
+            for (int p = 0; p < NBR; ++p) {
+                if (nb0 + p < deg) {
+#pragma unroll
+                    for (int j = 0; j < PPP; ++j) issue_piece(1 + p, j, j < 4 ? ix[p][j < 4 ? j : 0] : ixt[KG > 8 ? p : 0]);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int p = 0; p < NBR; ++p) {
+                if (nb0 + p < deg) {
+                    f32x4v f[NM];
+                    read_plane(1 + p, f);
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) sf[m] += f[m];
+                }
+            }
+            if (nb0 + NBR >= deg && tn < t_end) load_idx(tn, 0);            // (the registers held this tile's later rounds)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every fragment of this tile is in registers
+        WPROF(p2);
+        // ---- MFMA phase; in its shadow: the next tile's rows into the (now free) planes, then the indices of the
+        // tile after it, and the previous tile's four stores
+        const bool nxt = tn < t_end;
+        const bool nxt2 = tn2 < t_end && deg > 0 && deg <= NBR;
+        auto side = [&](int k) {
+            if (nxt && k < NPL * PPP) issue_round0_piece(tn, k);
+            if (k == NS - 1 && nxt2) load_idx(tn2, 0);
+            if (k >= NS - 4 && prev_row != nullptr)
+                *reinterpret_cast<f32x4v*>(prev_row + 16 * (k - (NS - 4))) = prev[k - (NS - 4)];
+        };
+        f32x4v acc[4];
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) acc[fb] = bias[fb];
+        if (deg > 0) wave_mfma_tile<NM, true>(wl0, wl1, xf, sf, acc, side);
+        else wave_mfma_tile<NM, false>(wl0, wl1, xf, sf, acc, side);
+#ifdef JOVA_WAVE_PROFILE
+        asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));     // the MFMAs have retired
+#endif
+        WPROF(p4);
+        // epilogue: lane (i, q) holds output features 16 fb + 4 q .. + 3 of atom i.  Rows past the bucket's end were
+        // computed from the clamped (= last) row and store that row's values again.
+        const bool live = i < rows;
+        prev_row = out + (size_t)(bstart + lrow0 + min(i, rows - 1)) * 64 + 4 * q;
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+            f32x4v v = acc[fb];
+            if (relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (STATS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float u = live ? v[r] : 0.f;
+                    ssum[fb][r] += u;
+                    ssq[fb][r] += u * u;
+                }
+            }
+            prev[fb] = v;
+        }
+#ifdef JOVA_WAVE_PROFILE
+        const unsigned long long p5 = __builtin_readcyclecounter();
+        pf_wait += p1 - p0; pf_read += p2 - p1; pf_mfma += p4 - p2; pf_epi += p5 - p4;
+#endif
+    }
+    if (prev_row != nullptr) {
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) *reinterpret_cast<f32x4v*>(prev_row + 16 * fb) = prev[fb];
+    }
+#ifdef JOVA_WAVE_PROFILE
+    if (lane == 0 && blockIdx.x < 256) {
+        unsigned long long* o = g_wave_prof + (blockIdx.x * 8 + wave) * 8;
+        o[0] = pf_wait; o[1] = pf_read; o[2] = pf_start - pf_entry; o[3] = pf_mfma; o[4] = pf_epi;
+        if (wave == 0) {                             // wall-clock (100 MHz) entry / exit of the workgroup's first wave
+            g_wave_prof[256 * 64 + blockIdx.x * 2] = pf_wall0;
+            g_wave_prof[256 * 64 + blockIdx.x * 2 + 1] = wall_clock64();
+        }
+        o[5] = __builtin_readcyclecounter() - pf_start; o[6] = n_done; o[7] = deg;
+    }
+#endif
+    if (STATS) {
+        // per-lane fp32 partials (a few dozen atoms each) -> fp64, over the 16 atom lanes, over the 8 waves, one atomic
+        // per column and workgroup
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();                             // every wave is done with its planes
+        double* red = reinterpret_cast<double*>(lds + 2 * WMAT_F);           // [8 waves][2][64]
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // (fp32 over the 16 atom lanes: each partial covers <= ~10 atoms, 160 values in all; fp64 from here on)
+                float a = ssum[fb][r], b = ssq[fb][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    a += __shfl_xor(a, o, 64);
+                    b += __shfl_xor(b, o, 64);
+                }
+                if (i == 0) {
+                    red[(wave * 2 + 0) * 64 + 16 * fb + 4 * q + r] = (double)a;
+                    red[(wave * 2 + 1) * 64 + 16 * fb + 4 * q + r] = (double)b;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            double a = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) a += red[w * 128 + tid];
+            atomicAdd(&stats[tid], a);               // stats = [2][64]: sums, then sums of squares
+        }
+    }
+}
+
 // ================================================================================================ C ABI
 static int g_num_cu = 0;
 static hipError_t num_cu_cached() {
@@ -1868,10 +2290,54 @@ static int make_plan(const int64_t* dsh, int64_t n_atoms, int nbp, int slots_per
     return blk > 0 ? blk : 1;
 }
 
+// Work split of the wave-private forward: workgroups per bucket in proportion to its cost (a tile of degree d costs
+// one MFMA phase -- about half of one for d = 0 -- plus a share per extra gather round), <= num_wg workgroups in all.
+static int make_wave_plan(const int64_t* dsh, int64_t n_atoms, int nbr, int num_wg, WavePlan& plan) {
+    memset(&plan, 0, sizeof(plan));
+    double cost[NB], total = 0.0;
+    for (int d = 0; d < NB; ++d) {
+        const long long st = dsh[2 * d], sz = dsh[2 * d + 1];
+        if (sz < 0 || st < 0 || st + sz > n_atoms) {
+            jova_set_error("deg_slice_host[%d] = (%lld, %lld) out of range for %lld atoms", d, st, sz, (long long)n_atoms);
+            return -1;
+        }
+        plan.start[d] = (int)st;
+        plan.size[d] = (int)sz;
+        // cycles per tile relative to a degree-1 tile, measured with in-kernel stamps on the config-4 batch
+        // (tools/prof_wave.py): the MFMA phase is the same for every degree >= 1, the gather rounds are not
+        static const double rel3[NB] = {0.6, 1.0, 1.08, 1.18, 1.40, 1.46, 1.54, 1.78, 1.82, 1.90, 2.15};
+        static const double rel2[NB] = {0.6, 1.0, 1.08, 1.35, 1.45, 1.70, 1.80, 2.05, 2.15, 2.40, 2.50};
+        cost[d] = (double)((sz + WT - 1) / WT) * (nbr >= 3 ? rel3[d] : rel2[d]);
+        total += cost[d];
+    }
+    if (total <= 0.0) return 0;
+    int wgs[NB];
+    for (double target = total / num_wg;; target *= 1.02) {
+        int sum = 0;
+        for (int d = 0; d < NB; ++d) {
+            const long long tl = (plan.size[d] + WT - 1) / WT;
+            long long w = cost[d] > 0.0 ? (long long)(cost[d] / target + 0.999) : 0;
+            if (w > (tl + 7) / 8) w = (tl + 7) / 8;          // at least one tile per wave
+            if (cost[d] > 0.0 && w < 1) w = 1;
+            wgs[d] = (int)w;
+            sum += wgs[d];
+        }
+        if (sum <= num_wg) break;
+    }
+    int blk = 0;
+    for (int k = 0; k < NB; ++k) {                       // dispatch order: descending degree
+        plan.first[k] = blk;
+        blk += wgs[NB - 1 - k];
+    }
+    plan.first[NB] = blk;
+    return blk;
+}
+
 extern "C" size_t jova_graphconv_workspace_floats(int f_in, int f_out) {
     const int kh = (f_in + 1) / 2, ncb = (f_out + 31) / 32, kg = (f_in + 7) / 8;
     const size_t a = (size_t)21 * kh * ncb * 64, b = (size_t)21 * ncb * kg * 256;
-    return a > b ? a : b;
+    const size_t c = (size_t)21 * 4 * ((kg + 1) / 2) * 256;                 // wave-private form (f_out = 64)
+    return std::max(a, std::max(b, c));
 }
 
 extern "C" size_t jova_graphconv_bwd_scratch_floats(void) { return (size_t)21 * 64 * DWP_LD; }
@@ -1911,6 +2377,28 @@ extern "C" int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t l
     if (!atoms_is_i64 && (kg == 8 || kg == 10) && ld_atoms >= 8 * kg && (ld_atoms & 3) == 0 &&
         n_atoms < (1 << 24) && n_atoms * ld_atoms < (1ll << 31) && (((uintptr_t)atoms) & 15) == 0 &&
         !getenv("JOVA_GRAPHCONV_NO_DMA")) {
+        // wave-private form: f_out = 64, bucket sizes known on the host, output rows 16-byte aligned
+        static int wave_env = -1;
+        if (wave_env < 0) wave_env = getenv("JOVA_FWD_OLD") ? 0 : 1;
+        if (wave_env && f_out == 64 && deg_slice_host && (((uintptr_t)out) & 15) == 0) {
+            JOVA_CHECK_HIP(num_cu_cached());
+            const int nm = kg / 2;
+            WavePlan wplan;
+            const int nblk = make_wave_plan(deg_slice_host, n_atoms, kg == 8 ? 3 : 2, g_num_cu, wplan);
+            if (nblk < 0) return JOVA_ERR_ARG;
+            if (nblk == 0) return JOVA_OK;
+            (void)nm;
+            // (the weights go from the layer's matrices into LDS fragment order inside the kernel: no re-pack launch, the
+            // workspace is not used by this form)
+#define GC_WAVE(KG_, NPL_, ST_)                                                                                        \
+    hipLaunchKernelGGL((graphconv_fwd_wave_kernel<KG_, NPL_, ST_>), dim3(nblk), dim3(512), 0, s, (const float*)atoms,  \
+                       (int)n_atoms, (int)ld_atoms, f_in, P, relu, out, bn_stats, wplan)
+            if (kg == 8) { if (bn_stats) GC_WAVE(8, 4, true); else GC_WAVE(8, 4, false); }
+            else { if (bn_stats) GC_WAVE(10, 3, true); else GC_WAVE(10, 3, false); }
+#undef GC_WAVE
+            JOVA_CHECK_LAUNCH("graphconv_fwd_wave");
+            return JOVA_OK;
+        }
         const long long qtotal = 21ll * ncb * kg * 256;
         hipLaunchKernelGGL(graphconv_pack_dma_kernel, dim3(cdiv(qtotal, 256)), dim3(256), 0, s, P, f_in, f_out, kg, ncb,
                            packed_ws);
