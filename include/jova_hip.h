@@ -90,6 +90,22 @@ int jova_block_order(const int64_t* deg_slice_host, int64_t n_atoms, int32_t* or
 int jova_adj_reverse_pos(int64_t n_atoms, const int64_t* deg_slice, const int32_t* const* adj, uint8_t* rev_pos,
                          void* stream);
 
+/* ---- batch merge: ConvMol.agglomerate_mols, jova/feat/mol_graphs.py:272-383 (called per mini-batch from
+ * process_gconv_view_data, jova/data/data.py:290).  HOST-only, no GPU call; every pointer is a HOST pointer.
+ * Per molecule m (atoms already degree-sorted as ConvMol.__init__ leaves them, mol_graphs.py:54-201): n_atoms[m],
+ * feats[m] int64 [n, n_feat], deg_list[m] int64 [n] (non-decreasing), nbr_flat[m] int64 [sum deg] = the neighbour lists
+ * in atom order, local ids.  Outputs (the caller's upload image, typically pinned): nodes [N, n_feat], deg_slice [11,2],
+ * membership [N], adj = adj_1 | .. | adj_10 concatenated (adj_d int32 [n_d, d]), mol_off int32 [n_mols + 1] (prefix sums
+ * of n_atoms), block_order (optional, as jova_block_order), symmetric (optional: 1 iff the adjacency is a simple
+ * undirected graph, the host counterpart of jova_adj_symmetry), atoms_f32 (optional: the fp32 copy of nodes with rows
+ * zero padded to ld_f32 floats, as jova_atoms_to_f32), rev_pos (optional, uint8 [sum_d n_d * d], as
+ * jova_adj_reverse_pos).  Same integers as the reference, bit for bit. */
+int jova_collate_gconv(int n_mols, const int32_t* n_atoms, const int64_t* const* feats, const int64_t* const* deg_list,
+                       const int64_t* const* nbr_flat, int n_feat, int64_t* nodes_out, int64_t* deg_slice_out,
+                       int64_t* membership_out, int32_t* adj_out, int32_t* mol_off_out, int32_t* block_order_out_or_null,
+                       int* symmetric_out_or_null, float* atoms_f32_out_or_null, int ld_f32,
+                       uint8_t* rev_pos_out_or_null);
+
 /* ---- GraphGather2D: jova/nn/layers.py:427-437 ---------------------------------------------------------------
  * mol_off int32 [batch+1] = prefix sums of n_atoms_lst; out [a_max, batch, g] = zero-padded contiguous chunks. */
 int jova_gather2d_fwd(const float* x, const int32_t* mol_off, int a_max, int batch, int g, float* out, void* stream);

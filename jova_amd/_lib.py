@@ -17,6 +17,7 @@ _SIGS = {
     "jova_atoms_to_f32": "pqiipp",
     "jova_graphconv_bwd": "piqqiippp" + "pppp" + "ppppppp",
     "jova_adj_symmetry": "qpppp",
+    "jova_collate_gconv": "ipppp" + "i" + "ppppppp" + "pip",
     "jova_graphpool_fwd": "pqipp" + "pppp",
     "jova_block_order": "pqp",
     "jova_graphpool_bwd": "ppqipp" + "ppippp",

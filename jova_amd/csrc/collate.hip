@@ -1,0 +1,142 @@
+// Host-side batch collation (no GPU code): the batch merge of ConvMol.agglomerate_mols, reference
+// jova/feat/mol_graphs.py:272-383, written straight into the caller's (pinned) upload image.
+//
+// The reference runs a Python loop over every neighbour of every atom (15.5 ms per 128 molecules);
+// at a 7 ms training step that is the bottleneck, so the merge is native and runs on a prefetch thread
+// (jova_amd/data/collate.py: BatchPrefetcher).  Output layout = the reference's, bit for bit:
+//   atoms ordered degree-major, molecule-minor; deg_slice[b] = (running start, size), empty buckets NOT zeroed;
+//   membership[i] = molecule of final atom i; adj_d int32 [n_d, d] holds final atom ids in each atom's own neighbour
+//   order.
+#include "common.h"
+#include "jova_hip.h"
+#include <string.h>
+#include <vector>
+
+#define CNB 11
+
+extern "C" int jova_collate_gconv(int n_mols, const int32_t* n_atoms, const int64_t* const* feats,
+                                  const int64_t* const* deg_list, const int64_t* const* nbr_flat, int n_feat,
+                                  int64_t* nodes_out, int64_t* deg_slice_out, int64_t* membership_out,
+                                  int32_t* adj_out, int32_t* mol_off_out, int32_t* block_order_out_or_null,
+                                  int* symmetric_out_or_null, float* atoms_f32_out_or_null, int ld_f32,
+                                  uint8_t* rev_pos_out_or_null) {
+    JOVA_CHECK_ARG(n_mols >= 0 && n_feat >= 1 && deg_slice_out && mol_off_out, "collate_gconv: bad argument");
+    JOVA_CHECK_ARG(n_mols == 0 || (n_atoms && feats && deg_list && nbr_flat && nodes_out && membership_out && adj_out),
+                   "collate_gconv: null pointer");
+    // bucket sizes per molecule (deg_list is non-decreasing: atoms are degree-sorted inside a molecule)
+    std::vector<int64_t> size((size_t)CNB * (n_mols > 0 ? n_mols : 1), 0);
+    int64_t deg_sizes[CNB] = {0}, total = 0;
+    mol_off_out[0] = 0;
+    for (int m = 0; m < n_mols; ++m) {
+        const int n = n_atoms[m];
+        JOVA_CHECK_ARG(n >= 0, "collate_gconv: molecule %d has %d atoms", m, n);
+        int64_t prev = 0;
+        for (int a = 0; a < n; ++a) {
+            const int64_t d = deg_list[m][a];
+            JOVA_CHECK_ARG(d >= prev && d < CNB, "collate_gconv: molecule %d: degrees must be sorted and <= 10", m);
+            prev = d;
+            ++size[(size_t)d * n_mols + m];
+        }
+        total += n;
+        JOVA_CHECK_ARG(total < (1ll << 31), "collate_gconv: more than 2^31 atoms");
+        mol_off_out[m + 1] = (int32_t)total;
+    }
+    for (int b = 0; b < CNB; ++b)
+        for (int m = 0; m < n_mols; ++m) deg_sizes[b] += size[(size_t)b * n_mols + m];
+    int64_t deg_start[CNB], adj_base[CNB];
+    {
+        int64_t run = 0, erun = 0;
+        for (int b = 0; b < CNB; ++b) {
+            deg_start[b] = run;
+            adj_base[b] = erun;
+            run += deg_sizes[b];
+            erun += deg_sizes[b] * b;
+            deg_slice_out[2 * b] = deg_start[b];             // (mol_graphs.py:304-314: running start, empty or not)
+            deg_slice_out[2 * b + 1] = deg_sizes[b];
+        }
+    }
+    // first final row of (bucket, molecule); then the final row of every atom
+    std::vector<int64_t> first((size_t)CNB * (n_mols > 0 ? n_mols : 1));
+    for (int b = 0; b < CNB; ++b) {
+        int64_t run = deg_start[b];
+        for (int m = 0; m < n_mols; ++m) {
+            first[(size_t)b * n_mols + m] = run;
+            run += size[(size_t)b * n_mols + m];
+        }
+    }
+    std::vector<int32_t> final_of((size_t)(total > 0 ? total : 1));
+    for (int m = 0; m < n_mols; ++m) {
+        const int n = n_atoms[m];
+        const int64_t base = mol_off_out[m];
+        int64_t cur_d = -1, blk = 0;
+        for (int a = 0; a < n; ++a) {
+            const int64_t d = deg_list[m][a];
+            if (d != cur_d) { cur_d = d; blk = 0; }
+            const int64_t f = first[(size_t)d * n_mols + m] + blk++;
+            final_of[(size_t)(base + a)] = (int32_t)f;
+            memcpy(nodes_out + f * n_feat, feats[m] + (int64_t)a * n_feat, sizeof(int64_t) * (size_t)n_feat);
+            membership_out[f] = m;
+        }
+    }
+    // adjacency: local degree-sorted ids -> final rows
+    for (int m = 0; m < n_mols; ++m) {
+        const int n = n_atoms[m];
+        const int64_t base = mol_off_out[m];
+        int64_t ptr = 0;
+        for (int a = 0; a < n; ++a) {
+            const int64_t d = deg_list[m][a];
+            if (d == 0) continue;
+            int32_t* row = adj_out + adj_base[d] + ((int64_t)final_of[(size_t)(base + a)] - deg_start[d]) * d;
+            for (int64_t k = 0; k < d; ++k) {
+                const int64_t nb = nbr_flat[m][ptr + k];
+                JOVA_CHECK_ARG(nb >= 0 && nb < n, "collate_gconv: molecule %d: neighbour index %lld out of range", m, (long long)nb);
+                row[k] = final_of[(size_t)(base + nb)];
+            }
+            ptr += d;
+        }
+    }
+    if (block_order_out_or_null && total > 0) {
+        const int rc = jova_block_order(deg_slice_out, total, block_order_out_or_null);
+        if (rc != JOVA_OK) return rc;
+    }
+    if (atoms_f32_out_or_null) {
+        // fp32 copy of the (small integer) atom features, rows zero padded to ld_f32 floats: what the graph-conv kernels
+        // read (jova_atoms_to_f32 makes the same image on the device)
+        JOVA_CHECK_ARG(ld_f32 >= n_feat, "collate_gconv: ld_f32 %d < n_feat %d", ld_f32, n_feat);
+        for (int64_t r = 0; r < total; ++r) {
+            const int64_t* src = nodes_out + r * n_feat;
+            float* dst = atoms_f32_out_or_null + r * ld_f32;
+            for (int c = 0; c < n_feat; ++c) dst[c] = (float)src[c];
+            for (int c = n_feat; c < ld_f32; ++c) dst[c] = 0.f;
+        }
+    }
+    if (symmetric_out_or_null || rev_pos_out_or_null) {
+        // simple undirected graph?  (every list duplicate- and self-loop-free, i in nbr(j) <=> j in nbr(i): then the
+        // backward scatters run as gathers, see jova_adj_symmetry)
+        std::vector<int8_t> deg_of((size_t)(total > 0 ? total : 1));
+        for (int b = 0; b < CNB; ++b)
+            for (int64_t r = 0; r < deg_sizes[b]; ++r) deg_of[(size_t)(deg_start[b] + r)] = (int8_t)b;
+        // rev_pos (as jova_adj_reverse_pos): for atom i's k-th neighbour j the 1-based position of i in j's list, 0xFF
+        // if it is not there; laid out like adj_1 | .. | adj_10
+        bool ok = true;
+        for (int64_t i = 0; i < total; ++i) {
+            const int d = deg_of[(size_t)i];
+            const int64_t e0 = adj_base[d] + (i - deg_start[d]) * d;
+            const int32_t* row = adj_out + e0;
+            for (int k = 0; k < d; ++k) {
+                const int64_t j = row[k];
+                if (j == i) ok = false;
+                for (int u = 0; u < k; ++u) ok = ok && row[u] != j;
+                const int dj = deg_of[(size_t)j];
+                const int32_t* rj = adj_out + adj_base[dj] + (j - deg_start[dj]) * dj;
+                int pos = 0;
+                for (int u = dj - 1; u >= 0; --u)
+                    if (rj[u] == (int32_t)i) pos = u + 1;           // first occurrence, as the device kernel's ffs
+                ok = ok && pos != 0;
+                if (rev_pos_out_or_null) rev_pos_out_or_null[e0 + k] = pos ? (uint8_t)pos : (uint8_t)0xFF;
+            }
+        }
+        if (symmetric_out_or_null) *symmetric_out_or_null = ok ? 1 : 0;
+    }
+    return JOVA_OK;
+}

@@ -63,7 +63,7 @@ class Topology(object):
     """Device-side view of one batch graph: the [1], [3], [4:] entries of the reference's gconv input list
     (jova/data/data.py:291-296) plus what the kernels derive from them once per batch."""
 
-    def __init__(self, deg_slice, adj_lists, n_atoms_lst, n_atoms):
+    def __init__(self, deg_slice, adj_lists, n_atoms_lst, n_atoms, sym_host=None):
         dev = deg_slice.device
         _lib.require_gpu(deg_slice)
         self.deg_slice = _c(deg_slice.to(torch.int64))
@@ -78,11 +78,16 @@ class Topology(object):
         self.adj_ptrs = ptr_array(self.adj)
         self.n_atoms = int(n_atoms)
         self.n_atoms_lst = [int(v) for v in n_atoms_lst] if n_atoms_lst is not None else None
-        self.sym_flag = torch.empty(1, dtype=torch.int32, device=dev)
-        call("jova_adj_symmetry", self.n_atoms, P(self.deg_slice), self.adj_ptrs, P(self.sym_flag), stream())
+        if sym_host is None:
+            self.sym_flag = torch.empty(1, dtype=torch.int32, device=dev)
+            call("jova_adj_symmetry", self.n_atoms, P(self.deg_slice), self.adj_ptrs, P(self.sym_flag), stream())
+        else:
+            # the collator checked the lists on the host (jova_collate_gconv): no kernel on a stream that may not have
+            # the uploaded lists yet (prefetch thread), and no device->host read later
+            self.sym_flag = torch.full((1,), int(bool(sym_host)), dtype=torch.int32, device=dev)
         self._mol_off = None
         self._atoms_f32 = None
-        self._sym_host = None
+        self._sym_host = None if sym_host is None else bool(sym_host)
         self._deg_slice_host = None
         self._rev_pos = None
         self._block_order = None

@@ -103,9 +103,13 @@ class ProteinTable(object):
         table = np.concatenate(rows, axis=0) if rows else np.zeros((0, 1), np.int32)
         self.table = torch.from_numpy(np.ascontiguousarray(table)).to(device)
 
+    def batch_meta(self, prot_x):
+        """[(source, name), ...] -> host int32 [B, 2] = (first table row, segment count) of each pair's protein."""
+        return np.array([self.row_of[prot[1]] for prot in prot_x], dtype=np.int32).reshape(len(prot_x), 2)
+
     def batch(self, prot_x, device):
         """[(source, name), ...] -> (row offsets int32 [B], segment counts int32 [B], P_max)."""
-        meta = np.array([self.row_of[prot[1]] for prot in prot_x], dtype=np.int32)
+        meta = self.batch_meta(prot_x)
         dev = torch.from_numpy(meta).to(device, non_blocking=True)
         return dev[:, 0].contiguous(), dev[:, 1].contiguous(), int(meta[:, 1].max())
 

@@ -836,3 +836,29 @@ def test_config4_graph_stack_vs_oracle(device):
     assert F_.NonsatFunction.last_n_eval.cpu().tolist()[0] == n_eval
     H.assert_close(og_, want.detach(), tol=1e-5, what="config 4: gather2d + nonsat")
     H.assert_close(xd.grad, xc.grad, tol=1e-5, what="config 4: gather2d + nonsat backward")
+
+
+@pytest.mark.parametrize("shape,n_mols", [("davis", 64), ("graph4k", 300)])
+def test_collator_host_images_equal_device_kernels(device, shape, n_mols):
+    """The native collator ships two derived images in its one upload: the fp32 copy of the atom features and the
+    reverse edge positions.  They must be what the device kernels (jova_atoms_to_f32, jova_adj_reverse_pos) make."""
+    from jova_amd import synth
+    from jova_amd.data.collate import gconv_input_list
+    from jova_amd.feat.mol_graphs import ConvMol
+    from jova_amd.nn import functional as F_
+    pool = synth.SyntheticPool(shape, seed=3, n_mols=n_mols, n_prots=2)
+    mols = [ConvMol(f, a, smiles=str(i)) for i, (f, a) in enumerate(pool.mols)]
+    gl = gconv_input_list(mols, device)
+    topo = gl[1]._jova_topology
+    n, f = gl[0].shape
+    ld = F_._atoms_ld(f)
+    want = torch.empty((n, ld), device=device)
+    F_.call("jova_atoms_to_f32", F_.P(gl[0]), n, f, ld, F_.P(want), F_.stream())
+    assert torch.equal(topo.atoms_f32(gl[0]), want)
+    e = sum(int(a.numel()) for a in gl[4:])
+    rp = torch.empty(e, dtype=torch.uint8, device=device)
+    F_.call("jova_adj_reverse_pos", n, F_.P(topo.deg_slice), topo.adj_ptrs, F_.P(rp), F_.stream())
+    assert topo.symmetric and torch.equal(topo.rev_pos[:e], rp)
+    flag = torch.zeros(1, dtype=torch.int32, device=device)
+    F_.call("jova_adj_symmetry", n, F_.P(topo.deg_slice), topo.adj_ptrs, F_.P(flag), F_.stream())
+    assert int(flag.item()) == 1 == int(topo.sym_flag.item())

@@ -188,3 +188,72 @@ def test_product_path_refuses_cpu_tensors():
     gl = H.oracle_glist(H.unpack_mols(z), torch.zeros(int(z["nodes"].shape[0]), 8))
     with pytest.raises(RuntimeError, match="GPU"):
         GraphPool()(gl)
+
+
+# ---------------------------------------------------------------------------------------------- reference-shaped collators
+class _Prot(object):
+    def __init__(self, name):
+        self.name = name
+
+    def get_name(self):
+        return self.name
+
+
+class _EcfpMol(object):
+    def __init__(self, bits):
+        self.bits = bits
+
+    def get_array(self):
+        return self.bits
+
+
+@pytest.mark.parametrize("name", ["toy4", "deg0_b16", "hubs_b8", "pair_b2", "davis_b128"])
+def test_batch_collator_reference_api_is_bit_exact(name):
+    """batch_collator / process_gconv_view_data / process_ecfp_view_data with the reference's signatures and return
+    tuples (jova/data/data.py:166-306), fed duck-typed (mol, protein) pairs through DtiDataset items: the gconv list
+    equals the reference-made index golden bit for bit (native merge, jova_collate_gconv)."""
+    import torch
+    from jova_amd.data.data import DtiDataset, batch_collator
+    z = H.load("index_" + name)
+    raw = H.unpack_mols(z)
+    cms = [ConvMol(f, a, smiles=str(i)) for i, (f, a) in enumerate(raw)]
+    rng = np.random.RandomState(5)
+    prots = [_Prot("P%d" % (i % 3)) for i in range(len(cms))]
+    desc = {"P%d" % k: rng.normal(size=(1, 17)) for k in range(3)}
+    ecfps = [_EcfpMol((rng.uniform(size=32) < 0.2).astype(np.float64)) for _ in cms]
+    y = [np.array([float(i)]) for i in range(len(cms))]
+    w = [np.array([1.0]) for _ in cms]
+    ds = DtiDataset(x_s=(list(zip(ecfps, prots)), list(zip(cms, prots))), y_s=(y, y), w_s=(w, w))
+    batch = [ds[i] for i in range(len(ds))]
+    bsz, data = batch_collator(batch, desc, {"ecfp8": True, "weave": False, "gconv": True}, cuda_prot=False)
+    assert bsz == len(cms) and list(data) == ["ecfp8", "gconv"]
+    (mol_data, prots_tensor, prot_names, x_data), yv, wv = data["gconv"]
+    assert prot_names == [p.get_name() for p in prots] and x_data[0][0] is cms[0]
+    assert prots_tensor.dtype == torch.float32 and tuple(prots_tensor.shape) == (len(cms), 17)
+    assert np.array_equal(prots_tensor.numpy(), np.array([desc[n][0] for n in prot_names], dtype=np.float32))
+    assert float(yv[len(cms) - 1][0]) == len(cms) - 1.0 and float(wv[0][0]) == 1.0
+    atoms, deg_slice, memb, n_atoms = (t.cpu() if torch.is_tensor(t) else t for t in mol_data[:4])
+    assert atoms.dtype == torch.int64 and np.array_equal(atoms.numpy(), z["nodes"].astype(np.int64))
+    assert deg_slice.dtype == torch.int64 and np.array_equal(deg_slice.numpy(), z["deg_slice"])
+    assert np.array_equal(memb.numpy(), z["membership"]) and list(n_atoms) == list(z["n_atoms"])
+    assert len(mol_data) == 14
+    for d in range(1, 11):
+        a = mol_data[3 + d].cpu()
+        assert a.dtype == torch.int32 and np.array_equal(a.numpy(), z["adj_%d" % d])
+    (mols_tensor, prots2, names2, _), _, _ = data["ecfp8"]
+    assert mols_tensor.dtype == torch.float32 and np.array_equal(mols_tensor.cpu().numpy(), np.array([e.bits for e in ecfps], np.float32))
+    assert names2 == prot_names
+    with pytest.raises(NotImplementedError):
+        batch_collator(batch, desc, "weave")
+
+
+def test_native_collate_rejects_bad_molecules():
+    from jova_amd.data.collate import gconv_input_list
+    import torch
+    m = ConvMol(np.zeros((3, 75), dtype=np.int64), [[1], [0, 2], [1]], smiles="a")
+    m.nbr_flat = m.nbr_flat.copy()
+    m.nbr_flat[0] = 7                                   # neighbour index outside the molecule
+    with pytest.raises(RuntimeError, match="out of range"):
+        gconv_input_list([m], torch.device("cpu"))
+    empty = gconv_input_list([], torch.device("cpu"))   # an empty batch is legal
+    assert empty[0].shape[0] == 0 and empty[3] == []
