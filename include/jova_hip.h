@@ -210,6 +210,17 @@ int jova_sgd_step(float* params, const float* grads, float* momentum_buf_or_null
 int jova_adamax_step(float* params, const float* grads, float* exp_avg, float* exp_inf, int64_t n, float lr,
                      float beta1, float beta2, float eps, float weight_decay, float grad_scale, int step, void* stream);
 
+/* torch.optim.Adam / RMSprop / Adagrad / Adadelta (the optimizer table of proj/dti/train_joint_attn.py:276-285) on the flat
+ * parameter / gradient buffers.  kind 2 = adam (h0 beta1, h1 beta2, h2 eps; state1 exp_avg, state2 exp_avg_sq),
+ * 3 = rmsprop (h0 alpha, h1 eps, h2 momentum; state1 square_avg, state2 momentum buffer or NULL when h2 == 0),
+ * 4 = adagrad (h0 lr_decay, h1 eps; state1 sum), 5 = adadelta (h0 rho, h1 eps; state1 square_avg, state2 acc_delta).
+ * step = 1-based step count; gradient used = grads * grad_scale + weight_decay * params. */
+int jova_optim_step(int kind, float* params, const float* grads, float* state1, float* state2_or_null, int64_t n,
+                    float lr, float weight_decay, float grad_scale, int step, float h0, float h1, float h2, void* stream);
+/* *flag |= 1 if x holds a NaN or an infinity: the fail-fast of proj/dti/train_joint_attn.py:468-470 without a
+ * device->host read per batch */
+int jova_nonfinite_flag(const float* x, int64_t n, int* flag, void* stream);
+
 /* ---- element-wise helpers (nn.ReLU and gradient bookkeeping) --------------------------------------------------- */
 int jova_relu_fwd(const float* x, int64_t n, float* y, void* stream);
 int jova_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* stream);

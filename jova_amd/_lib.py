@@ -44,6 +44,8 @@ _SIGS = {
     "jova_mse_loss": "pppippp",
     "jova_sgd_step": "pppq" + "ffffi" + "p",
     "jova_adamax_step": "ppppq" + "ffffffi" + "p",
+    "jova_optim_step": "ipppp" + "qfffi" + "fffp",
+    "jova_nonfinite_flag": "pqpp",
     "jova_relu_fwd": "pqpp",
     "jova_relu_bwd": "ppqpp",
     "jova_axpy": "pfqpp",

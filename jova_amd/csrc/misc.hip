@@ -272,6 +272,81 @@ extern "C" int jova_mse_loss(const float* outputs, const float* weights, const f
     return JOVA_OK;
 }
 
+// adam / rmsprop / adagrad / adadelta on the flat buffers, torch.optim semantics (the reference builds its optimizer from
+// torch.optim by name, proj/dti/train_joint_attn.py:276-296); weight decay is the coupled L2 form (d = g + wd p)
+__global__ void optim_kernel(int kind, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ s1,
+                             float* __restrict__ s2, long long n, float lr, float wd, float gscale, float h0, float h1,
+                             float h2, float c0, float c1) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+         e += (long long)gridDim.x * blockDim.x) {
+        const float d = g[e] * gscale + wd * p[e];
+        if (kind == 2) {                         // adam: h0 = beta1, h1 = beta2, h2 = eps, c0 = 1 - b1^t, c1 = sqrt(1 - b2^t)
+            const float m = h0 * s1[e] + (1.f - h0) * d;
+            const float v = h1 * s2[e] + (1.f - h1) * d * d;
+            s1[e] = m;
+            s2[e] = v;
+            p[e] -= (lr / c0) * m / (sqrtf(v) / c1 + h2);
+        } else if (kind == 3) {                  // rmsprop: h0 = alpha, h1 = eps, h2 = momentum (s2 = momentum buffer)
+            const float sq = h0 * s1[e] + (1.f - h0) * d * d;
+            s1[e] = sq;
+            const float avg = sqrtf(sq) + h1;
+            if (h2 > 0.f) {
+                const float b = h2 * s2[e] + d / avg;
+                s2[e] = b;
+                p[e] -= lr * b;
+            } else {
+                p[e] -= lr * d / avg;
+            }
+        } else if (kind == 4) {                  // adagrad: h1 = eps, c0 = lr / (1 + (t - 1) lr_decay)
+            const float sum = s1[e] + d * d;
+            s1[e] = sum;
+            p[e] -= c0 * d / (sqrtf(sum) + h1);
+        } else {                                 // adadelta: h0 = rho, h1 = eps (s1 = square_avg, s2 = acc_delta)
+            const float sq = h0 * s1[e] + (1.f - h0) * d * d;
+            const float delta = sqrtf(s2[e] + h1) / sqrtf(sq + h1) * d;
+            s1[e] = sq;
+            s2[e] = h0 * s2[e] + (1.f - h0) * delta * delta;
+            p[e] -= lr * delta;
+        }
+    }
+}
+
+extern "C" int jova_optim_step(int kind, float* params, const float* grads, float* state1, float* state2_or_null,
+                               int64_t n, float lr, float weight_decay, float grad_scale, int step, float h0, float h1,
+                               float h2, void* stream) {
+    JOVA_CHECK_ARG(kind >= 2 && kind <= 5, "optim_step: kind %d (2 adam, 3 rmsprop, 4 adagrad, 5 adadelta)", kind);
+    JOVA_CHECK_ARG(params && grads && state1 && n >= 0 && step >= 1, "optim_step: bad argument");
+    JOVA_CHECK_ARG(state2_or_null || kind == 4 || (kind == 3 && h2 <= 0.f), "optim_step: this optimizer needs state2");
+    if (n == 0) return JOVA_OK;
+    float c0 = 1.f, c1 = 1.f;
+    if (kind == 2) {
+        c0 = (float)(1.0 - pow((double)h0, (double)step));
+        c1 = (float)sqrt(1.0 - pow((double)h1, (double)step));
+    } else if (kind == 4) {
+        c0 = (float)((double)lr / (1.0 + (double)(step - 1) * (double)h0));
+    }
+    hipLaunchKernelGGL(optim_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, kind, params, grads, state1,
+                       state2_or_null, (long long)n, lr, weight_decay, grad_scale, h0, h1, h2, c0, c1);
+    JOVA_CHECK_LAUNCH("optim_step");
+    return JOVA_OK;
+}
+
+// flag |= 1 if any of x[0..n) is NaN or infinite (the reference's fail-fast reads loss.item() every batch,
+// train_joint_attn.py:468-470; here the flag stays on the device and is read once per epoch)
+__global__ void nonfinite_flag_kernel(const float* __restrict__ x, long long n, int* __restrict__ flag) {
+    bool bad = false;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+        bad = bad || !isfinite(x[e]);
+    if (bad) atomicOr(flag, 1);
+}
+extern "C" int jova_nonfinite_flag(const float* x, int64_t n, int* flag, void* stream) {
+    JOVA_CHECK_ARG(x && flag && n >= 0, "nonfinite_flag: bad argument");
+    if (n == 0) return JOVA_OK;
+    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, flag);
+    JOVA_CHECK_LAUNCH("nonfinite_flag");
+    return JOVA_OK;
+}
+
 extern "C" int jova_sgd_step(float* params, const float* grads, float* momentum_buf_or_null, int64_t n, float lr,
                              float weight_decay, float momentum, float grad_scale, int first_step, void* stream) {
     JOVA_CHECK_ARG(params && grads && n >= 0, "sgd_step: bad argument");

@@ -202,6 +202,111 @@ def encoder_param_split(model, flat):
     return split
 
 
+# torch.optim constructor defaults of the optimizers in the reference's table (train_joint_attn.py:276-285)
+_OPTIM_DEFAULTS = {
+    "sgd": dict(lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False),
+    "adamax": dict(lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0),
+    "adam": dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False),
+    "rmsprop": dict(lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0.0, momentum=0.0, centered=False),
+    "adagrad": dict(lr=1e-2, lr_decay=0.0, weight_decay=0.0, initial_accumulator_value=0.0, eps=1e-10),
+    "adadelta": dict(lr=1.0, rho=0.9, eps=1e-6, weight_decay=0.0),
+}
+_OPTIM_KIND = {"adam": 2, "rmsprop": 3, "adagrad": 4, "adadelta": 5}
+
+
+def optimizer_kwargs(hparams):
+    """The reference's filter (train_joint_attn.py:288-296): keys ``optimizer__<name>__<arg>`` that name the chosen
+    optimizer, and ``optimizer__global__<arg>``, become constructor arguments."""
+    out = {}
+    key = hparams["optimizer"]
+    for k, v in hparams.items():
+        if "optimizer__" in k:
+            tup = k.split("__")
+            if key == tup[1] or tup[1] == "global":
+                out[tup[2]] = v
+    return out
+
+
+class FlatOptimizer(object):
+    """One optimizer step = one kernel over the flat parameter / gradient buffers (torch.optim semantics)."""
+
+    def __init__(self, flat, name, **kwargs):
+        self.name = name.lower()
+        if self.name not in _OPTIM_DEFAULTS:
+            if self.name in ("asgd", "rprop"):
+                raise NotImplementedError("optimizer %r is in the reference's table but has no flat-buffer kernel here "
+                                          "(sgd, adamax, adam, rmsprop, adagrad, adadelta do)" % name)
+            raise AssertionError("%s optimizer could not be found" % name)
+        self.opts = dict(_OPTIM_DEFAULTS[self.name])
+        for k, v in kwargs.items():
+            if k not in self.opts:                      # what torch.optim's constructor would say
+                raise TypeError("%s.__init__() got an unexpected keyword argument %r" % (self.name, k))
+            self.opts[k] = v
+        o = self.opts
+        if o.get("amsgrad") or o.get("centered") or o.get("nesterov") or o.get("dampening"):
+            raise NotImplementedError("amsgrad / centered / nesterov / dampening variants are not implemented")
+        self.flat = flat
+        self.lr = float(o["lr"])                        # current learning rate (a scheduler rewrites it)
+        self.initial_lr = self.lr
+        self.step_idx = 0
+        z = lambda: torch.zeros_like(flat.data)        # noqa: E731
+        self.s1 = self.s2 = None
+        if self.name == "sgd":
+            self.s1 = z() if o["momentum"] else None
+        elif self.name in ("adamax", "adam", "adadelta"):
+            self.s1, self.s2 = z(), z()
+        elif self.name == "rmsprop":
+            self.s1, self.s2 = z(), (z() if o["momentum"] else None)
+        elif self.name == "adagrad":
+            self.s1 = torch.full_like(flat.data, float(o["initial_accumulator_value"]))
+
+    def step(self, grad_scale=1.0):
+        f, o = self.flat, self.opts
+        self.step_idx += 1
+        P_, st = _lib.P, _lib.stream()
+        wd = float(o["weight_decay"])
+        if self.name == "sgd":
+            _lib.call("jova_sgd_step", P_(f.data), P_(f.grad), P_(self.s1), f.numel, self.lr, wd, float(o["momentum"]),
+                      grad_scale, int(self.step_idx == 1), st)
+        elif self.name == "adamax":
+            _lib.call("jova_adamax_step", P_(f.data), P_(f.grad), P_(self.s1), P_(self.s2), f.numel, self.lr,
+                      float(o["betas"][0]), float(o["betas"][1]), float(o["eps"]), wd, grad_scale, self.step_idx, st)
+        else:
+            h = {"adam": (o.get("betas", (0, 0))[0], o.get("betas", (0, 0))[1], o["eps"]),
+                 "rmsprop": (o.get("alpha", 0), o["eps"], o.get("momentum", 0)),
+                 "adagrad": (o.get("lr_decay", 0), o["eps"], 0.0),
+                 "adadelta": (o.get("rho", 0), o["eps"], 0.0)}[self.name]
+            _lib.call("jova_optim_step", _OPTIM_KIND[self.name], P_(f.data), P_(f.grad), P_(self.s1), P_(self.s2), f.numel,
+                      self.lr, wd, grad_scale, self.step_idx, float(h[0]), float(h[1]), float(h[2]), st)
+
+
+class StepLR(object):
+    """torch.optim.lr_scheduler.StepLR over a FlatOptimizer: lr = initial_lr * gamma ** (epoch // step_size).  The
+    reference creates StepLR(optimizer, step_size=500, gamma=0.01) and steps it once per epoch
+    (train_joint_attn.py:360, :529)."""
+
+    def __init__(self, optimizer, step_size=500, gamma=0.01):
+        self.optimizer, self.step_size, self.gamma = optimizer, int(step_size), float(gamma)
+        self.last_epoch = 0
+
+    def step(self):
+        self.last_epoch += 1
+        self.optimizer.lr = self.optimizer.initial_lr * self.gamma ** (self.last_epoch // self.step_size)
+
+    def get_last_lr(self):
+        return [self.optimizer.lr]
+
+
+class ExpAverage(object):
+    """jova/utils/math.py ExpAverage: value = beta * value + (1 - beta) * x (first update sets it)."""
+
+    def __init__(self, beta, v=0.):
+        self.beta, self.value = beta, v
+
+    def update(self, x):
+        self.value = self.beta * self.value + (1 - self.beta) * x
+
+
 class Trainer(object):
     """One training step = the body of the reference's batch loop (train_joint_attn.py:428-486), no host sync."""
 
@@ -213,10 +318,12 @@ class Trainer(object):
         self.flat = FlatParameters(model)
         self.world_size = world_size
         self.pg = process_group
-        self.opt = hparams.get("optimizer", "sgd").lower()
-        self.lr = float(hparams.get("optimizer__global__lr", 1e-3))
-        self.wd = float(hparams.get("optimizer__global__weight_decay", 0.0))
-        self.step_idx = 0
+        hp_opt = dict(hparams)
+        hp_opt.setdefault("optimizer", "sgd")
+        self.optimizer = FlatOptimizer(self.flat, hp_opt["optimizer"], **optimizer_kwargs(hp_opt))
+        self.scheduler = StepLR(self.optimizer, step_size=500, gamma=0.01)       # train_joint_attn.py:360
+        self.nan_flag = torch.zeros(1, dtype=torch.int32, device=self.flat.data.device)
+        self.loss_sum = torch.zeros(1, dtype=torch.float32, device=self.flat.data.device)
         self.sync = None
         # (force_sync: run the collectives of the N-rank step on a one-rank group -- rehearsal on a one-GPU box)
         self.collective = world_size > 1 or force_sync
@@ -226,11 +333,69 @@ class Trainer(object):
             split = encoder_param_split(model, self.flat)
             if split is not None:
                 self.sync = OverlappedGradSync(self.flat, split, process_group, self.reduce)
-        if self.opt == "adamax":
-            self.exp_avg = torch.zeros_like(self.flat.data)
-            self.exp_inf = torch.zeros_like(self.flat.data)
-        elif self.opt != "sgd":
-            raise NotImplementedError("optimizer %r: the HIP path implements sgd and adamax" % self.opt)
+
+    @property
+    def step_idx(self):
+        return self.optimizer.step_idx
+
+    @property
+    def lr(self):
+        return self.optimizer.lr
+
+    def fit(self, train_batches, eval_batches=None, n_epochs=1, evaluate=None, epoch_ckpt=(2, 1.0), log=None):
+        """The reference's epoch / phase loop (Jova.train, train_joint_attn.py:384-535) around ``step``.
+
+        train_batches / eval_batches: callables ``epoch -> iterable of DtiBatch`` (e.g. a BatchPrefetcher over a
+        ShardSampler epoch).  Per epoch: train phase (model.train(), every batch one ``step``), StepLR.step(), the
+        exponential-average guard on the epoch loss (:522-527), then the evaluation phase (model.eval(), no gradients)
+        whose mean score selects the best weights (:531-535; kept as a copy of the flat buffer, not a deep-copied state
+        dict).  ``evaluate(outputs, batch) -> device tensor score`` (e.g. metrics.score_on_device); host reads happen
+        once per phase: the non-finite flag, the epoch loss, the mean score.  Returns dict(score, epoch, history)."""
+        best = dict(score=-10000.0, epoch=-1)
+        best_wts = self.flat.data.clone()
+        best_bufs = {k: v.clone() for k, v in self.model.named_buffers()}
+        e_avg = ExpAverage(.01)
+        history = []
+        for epoch in range(n_epochs):
+            self.model.train()
+            self.loss_sum.zero_()
+            n_steps = 0
+            for batch in train_batches(epoch):
+                self.step(batch)
+                n_steps += 1
+            self.check_health()
+            if int(self.nan_flag.item()):                          # one read per epoch
+                history.append(dict(epoch=epoch, terminated="non-finite loss"))
+                break
+            ep_loss = float(self.loss_sum.item()) / max(n_steps, 1)
+            e_avg.update(ep_loss)
+            terminate = epoch_ckpt[0] > 1 and epoch % (epoch_ckpt[0] - 1) == 0 and epoch > 0 and e_avg.value > epoch_ckpt[1]
+            self.scheduler.step()
+            rec = dict(epoch=epoch, loss=ep_loss, lr=self.optimizer.lr)
+            if eval_batches is not None and evaluate is not None:
+                self.model.eval()
+                scores = []
+                with torch.no_grad():
+                    for batch in eval_batches(epoch):
+                        outputs = self.model(batch.model_input())
+                        scores.append(evaluate(outputs * batch.w, batch).reshape(1))
+                mean_score = float(torch.cat(scores).mean().item()) if scores else float("nan")
+                rec["score"] = mean_score
+                if best["score"] < mean_score:
+                    best.update(score=mean_score, epoch=epoch)
+                    best_wts.copy_(self.flat.data)
+                    best_bufs = {k: v.clone() for k, v in self.model.named_buffers()}
+            history.append(rec)
+            if log is not None:
+                log(rec)
+            if terminate:
+                break
+        if best["epoch"] >= 0:
+            self.flat.data.copy_(best_wts)
+            for k, v in self.model.named_buffers():
+                v.copy_(best_bufs[k])
+        best["history"] = history
+        return best
 
     def check_health(self):
         """Off the hot loop (the reference checks its loss every batch, train_joint_attn.py:468-470; here once per epoch
@@ -270,12 +435,9 @@ class Trainer(object):
             else:
                 self.reduce(self.flat.grad)
             scale = 1.0 / self.world_size
-        self.step_idx += 1
-        f = self.flat
-        if self.opt == "sgd":
-            _lib.call("jova_sgd_step", _lib.P(f.data), _lib.P(f.grad), None, f.numel, self.lr, self.wd, 0.0, scale, 1,
-                      _lib.stream())
-        else:
-            _lib.call("jova_adamax_step", _lib.P(f.data), _lib.P(f.grad), _lib.P(self.exp_avg), _lib.P(self.exp_inf),
-                      f.numel, self.lr, 0.9, 0.999, 1e-8, self.wd, scale, self.step_idx, _lib.stream())
+        # fail-fast flag and epoch loss stay on the device (train_joint_attn.py:468-470, :489, :523)
+        lv = loss.detach().reshape(1)
+        _lib.call("jova_nonfinite_flag", _lib.P(lv), 1, _lib.P(self.nan_flag), _lib.stream())
+        _lib.call("jova_axpy", _lib.P(lv), 1.0, 1, _lib.P(self.loss_sum), _lib.stream())
+        self.optimizer.step(scale)
         return loss, outputs

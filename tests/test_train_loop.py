@@ -1,0 +1,177 @@
+"""Row H of SURVEY.md section 8: the optimizer table and argument filter (proj/dti/train_joint_attn.py:276-296), StepLR
+(:360, :529) and the epoch / phase loop with its fail-fast (:384-535).
+
+The reference builds its optimizer and scheduler from torch.optim by name, so torch.optim / StepLR ARE the reference
+here: the flat-buffer kernels are run next to them on the same gradients (GPU), and a 2-epoch fit() of the small
+end-to-end model that crosses a scheduler boundary is compared with the fp64 oracle trained by torch.optim + StepLR."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+
+def test_optimizer_kwargs_filter_and_table():
+    from jova_amd.train import FlatOptimizer, optimizer_kwargs
+    hp = {"optimizer": "adam", "optimizer__global__lr": 1e-3, "optimizer__adam__eps": 1e-6, "optimizer__sgd__momentum": 0.9,
+          "optimizer__global__weight_decay": 0.01, "lr": 5}
+    assert optimizer_kwargs(hp) == {"lr": 1e-3, "eps": 1e-6, "weight_decay": 0.01}
+
+    class Flat:
+        data = torch.zeros(8)
+        grad = torch.zeros(8)
+        numel = 8
+    o = FlatOptimizer(Flat, "Adam", **optimizer_kwargs(hp))
+    assert o.opts["eps"] == 1e-6 and o.lr == 1e-3 and o.opts["betas"] == (0.9, 0.999)
+    with pytest.raises(TypeError, match="unexpected keyword"):
+        FlatOptimizer(Flat, "sgd", betas=(0.9, 0.99))
+    with pytest.raises(NotImplementedError):
+        FlatOptimizer(Flat, "Rprop")
+    with pytest.raises(AssertionError):
+        FlatOptimizer(Flat, "lbfgs")
+
+
+def test_step_lr_schedule():
+    from jova_amd.train import StepLR
+
+    class Opt:
+        lr = initial_lr = 0.5
+    s = StepLR(Opt, step_size=3, gamma=0.1)
+    p = torch.nn.Parameter(torch.zeros(1))
+    ref_opt = torch.optim.SGD([p], lr=0.5)
+    ref = torch.optim.lr_scheduler.StepLR(ref_opt, step_size=3, gamma=0.1)
+    for _ in range(8):
+        ref_opt.step()
+        ref.step()
+        s.step()
+        assert abs(s.get_last_lr()[0] - ref.get_last_lr()[0]) <= 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw", [
+    ("adam", dict(lr=2e-3, weight_decay=0.01)), ("adam", dict(lr=1e-3, betas=(0.8, 0.9), eps=1e-6)),
+    ("rmsprop", dict(lr=1e-3, alpha=0.9, weight_decay=0.001)), ("rmsprop", dict(lr=1e-3, momentum=0.7)),
+    ("adagrad", dict(lr=1e-2, lr_decay=0.1, initial_accumulator_value=0.2, weight_decay=0.01)),
+    ("adadelta", dict(rho=0.8, weight_decay=0.01)), ("adamax", dict(lr=4e-4, weight_decay=7e-4)),
+    ("sgd", dict(lr=4.7e-3, weight_decay=1.91e-2)), ("sgd", dict(lr=1e-2, momentum=0.9))])
+def test_flat_optimizers_and_step_lr_equal_torch_optim(device, name, kw):
+    """Eight steps on a 5 000-element flat buffer with a fresh random gradient each step; StepLR(step_size=3, gamma=0.1)
+    stepped after every step, so the learning rate changes twice inside the run."""
+    from jova_amd.train import FlatOptimizer, StepLR
+    g = torch.Generator().manual_seed(11)
+    n = 5000
+    p0 = torch.randn(n, generator=g)
+    cls = {"adam": torch.optim.Adam, "rmsprop": torch.optim.RMSprop, "adagrad": torch.optim.Adagrad,
+           "adadelta": torch.optim.Adadelta, "adamax": torch.optim.Adamax, "sgd": torch.optim.SGD}[name]
+    ref_p = torch.nn.Parameter(p0.double().clone())
+    ref_opt = cls([ref_p], **kw)
+    ref_sch = torch.optim.lr_scheduler.StepLR(ref_opt, step_size=3, gamma=0.1)
+
+    class Flat:
+        pass
+    flat = Flat()
+    flat.data, flat.grad, flat.numel = p0.clone().to(device), torch.zeros(n, device=device), n
+    opt = FlatOptimizer(flat, name, **kw)
+    sch = StepLR(opt, step_size=3, gamma=0.1)
+    for k in range(8):
+        grad = torch.randn(n, generator=g)
+        ref_p.grad = grad.double() * 0.5
+        ref_opt.step()
+        ref_sch.step()
+        flat.grad.copy_(grad.to(device))
+        opt.step(grad_scale=0.5)
+        sch.step()
+        assert abs(opt.lr - ref_opt.param_groups[0]["lr"]) <= 1e-12 * max(1.0, abs(opt.lr))
+    H.assert_close(flat.data, ref_p.detach().float(), tol=2e-6, what=name)
+
+
+@pytest.mark.gpu
+def test_nonfinite_flag_and_fail_fast(device):
+    from jova_amd._lib import P, call, stream
+    flag = torch.zeros(1, dtype=torch.int32, device=device)
+    x = torch.randn(1000, device=device)
+    call("jova_nonfinite_flag", P(x), 1000, P(flag), stream())
+    assert int(flag.item()) == 0
+    x[777] = float("inf")
+    call("jova_nonfinite_flag", P(x), 1000, P(flag), stream())
+    assert int(flag.item()) == 1
+    x[777] = 0.0
+    call("jova_nonfinite_flag", P(x), 1000, P(flag), stream())
+    assert int(flag.item()) == 1                                   # sticky until the host clears it
+
+
+@pytest.mark.gpu
+def test_fit_two_epochs_across_a_scheduler_boundary_vs_oracle(device):
+    """Trainer.fit on the small end-to-end model: 2 epochs x 2 batches, StepLR(step_size=1, gamma=0.01) so the second
+    epoch runs at lr / 100, evaluation phase in eval mode after each epoch.  Oracle: the fp64 restatement trained with
+    torch.optim.SGD + StepLR on the same batches; per-epoch mean losses, the learning rates and the evaluation-phase
+    outputs (BatchNorm running statistics, dropout off) must agree."""
+    from jova_amd.data.collate import DtiBatch, gconv_input_list
+    from jova_amd.feat.mol_graphs import ConvMol
+    from jova_amd.train import StepLR, Trainer, create_integrated_net
+    from oracle import mol_graphs as og
+    from oracle import nn_ref as R
+    z = H.load("e2e_small")
+    hp = H.hp(z)
+    hparams = {"attn_heads": hp["heads"], "attn_layers": hp["attn_layers"], "lin_dims": hp["lin_dims"], "output_dim": 1,
+               "latent_dim": hp["latent"], "dprob": 0.0, "optimizer": "sgd", "optimizer__global__lr": hp["lr"],
+               "optimizer__sgd__weight_decay": hp["wd"], "optimizer__adam__eps": 1.0,
+               "prot": {"model_types": ["pcnn2d"], "vocab_size": hp["vocab"], "window": hp["window"],
+                        "pcnn_num_layers": hp["pcnn_layers"], "embedding_dim": hp["emb"]},
+               "gconv": {"dim": hp["gconv_dim"]}, "ecfp8": {"dim": hp["ecfp_dim"]}}
+    prof = H.profile(z)
+    names = sorted(prof)
+    raw = H.unpack_mols(z)
+    net = create_integrated_net(hparams, prof)
+    net.load_state_dict(H.sd(z, "sd0."))
+    net = net.to(device)
+    tr = Trainer(net, hparams)
+    tr.scheduler = StepLR(tr.optimizer, step_size=1, gamma=0.01)
+    cms = [ConvMol(f, a, smiles=str(i)) for i, (f, a) in enumerate(raw)]
+    splits = [[0, 1, 2, 3, 4], [5, 6, 7, 3, 1]]                   # two batches of five pairs
+
+    def batch(ids):
+        gl = gconv_input_list([cms[i] for i in ids], device)
+        return DtiBatch(torch.from_numpy(z["ecfp"][ids]).to(device), gl, [("davis", names[z["prot_ids"][i]]) for i in ids],
+                        torch.from_numpy(z["y"][ids]).float().to(device), torch.from_numpy(z["w"][ids]).float().to(device))
+    eval_out = []
+
+    def evaluate(outputs, b):
+        eval_out.append(outputs.detach().cpu().double())
+        return -((outputs - b.y) ** 2).mean()
+    res = tr.fit(lambda ep: [batch(s) for s in splits], lambda ep: [batch(splits[0])], n_epochs=2, evaluate=evaluate)
+
+    # ---- oracle: fp64, torch.optim.SGD + StepLR, BatchNorm running statistics kept by hand for the eval phase
+    p = {k: (v.double().requires_grad_("running" not in k and "num_batches" not in k) if v.is_floating_point() else v.clone())
+         for k, v in H.sd(z, "sd0.").items()}
+    params = [v for v in p.values() if torch.is_tensor(v) and v.requires_grad]
+    opt = torch.optim.SGD(params, lr=hp["lr"], weight_decay=hp["wd"])
+    sch = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.01)
+
+    def obatch(ids):
+        b = og.agglomerate([og.SortedMol(*raw[i]) for i in ids])
+        gl = og.gconv_input_list(b)
+        glist = [torch.from_numpy(gl[0]), torch.from_numpy(gl[1]), torch.from_numpy(gl[2]), gl[3]] + \
+                [torch.from_numpy(a) for a in gl[4:]]
+        idx = og.embedding_indices([names[z["prot_ids"][i]] for i in ids], prof, fill_val=hp["vocab"])
+        return dict(ecfp=torch.from_numpy(z["ecfp"][ids]).double(), glist=glist, prot_idx=torch.from_numpy(idx))
+    want_losses = []
+    for epoch in range(2):
+        tot = 0.0
+        for ids in splits:
+            opt.zero_grad()
+            out, _ = R.dti_forward(p, obatch(ids), hp["heads"], hp["pcnn_layers"], len(hp["lin_dims"]))
+            loss = R.mse_loss(out, torch.from_numpy(z["w"][ids]), torch.from_numpy(z["y"][ids]))
+            loss.backward()
+            opt.step()
+            tot += float(loss)
+        sch.step()
+        want_losses.append(tot / 2)
+    hist = res["history"]
+    assert len(hist) == 2 and abs(hist[0]["lr"] - hp["lr"] * 0.01) < 1e-12 and abs(hist[1]["lr"] - hp["lr"] * 1e-4) < 1e-14
+    for h, wl in zip(hist, want_losses):
+        assert abs(h["loss"] - wl) <= 2e-5 * abs(wl), (h, wl)
+    assert res["epoch"] in (0, 1) and np.isfinite(res["score"]) and len(eval_out) == 2
+    assert not net.training                                        # the loop leaves the model in its last (eval) phase
+    # eval-mode outputs are finite and differ between the epochs (the weights moved)
+    assert torch.isfinite(eval_out[0]).all() and not torch.equal(eval_out[0], eval_out[1])
