@@ -221,6 +221,18 @@ int jova_optim_step(int kind, float* params, const float* grads, float* state1, 
  * device->host read per batch */
 int jova_nonfinite_flag(const float* x, int64_t n, int* flag, void* stream);
 
+/* ---- evaluation metrics ---------------------------------------------------------------------------------------- */
+/* The metrics Jova.evaluate takes per evaluation batch (proj/dti/train_joint_attn.py:335-343 through
+ * jova/metrics/all_metrics.py:80-104 and jova/metrics/cindex_measure.py:15-38, whose pair count is
+ * ext_src/c_swapped.c:324-365), on n samples resident on the device.  Samples with w == 0 are left out
+ * (all_metrics.py:651-652); labels and predictions are first un-z-scored as v * y_std + y_mean in double
+ * (NormalizationTransformer.untransform).  out6 = { rms, concordance index, pearson r^2, nanmean([ci, r2]) - rms,
+ * swapped pairs (ties in the prediction count 0.5), pairs with different labels }; a quantity the reference cannot
+ * form (no pair with different labels, constant input, no sample) is NaN.  ws16 = 128 bytes of device scratch.
+ * Pair counts are exact integers; n <= 2^20. */
+int jova_dti_metrics(const float* y_true, const float* y_pred, const float* w_or_null, int n, double y_std,
+                     double y_mean, double* ws16, double* out6, void* stream);
+
 /* ---- element-wise helpers (nn.ReLU and gradient bookkeeping) --------------------------------------------------- */
 int jova_relu_fwd(const float* x, int64_t n, float* y, void* stream);
 int jova_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* stream);

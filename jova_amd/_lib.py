@@ -46,11 +46,13 @@ _SIGS = {
     "jova_adamax_step": "ppppq" + "ffffffi" + "p",
     "jova_optim_step": "ipppp" + "qfffi" + "fffp",
     "jova_nonfinite_flag": "pqpp",
+    "jova_dti_metrics": "pppi" + "dd" + "ppp",
     "jova_relu_fwd": "pqpp",
     "jova_relu_bwd": "ppqpp",
     "jova_axpy": "pfqpp",
 }
-_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "q": ctypes.c_int64, "f": ctypes.c_float, "Q": ctypes.c_uint64}
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "q": ctypes.c_int64, "f": ctypes.c_float, "Q": ctypes.c_uint64,
+       "d": ctypes.c_double}
 
 EXPORTS = sorted(list(_SIGS) + ["jova_last_error", "jova_abi_version", "jova_nonsat_workspace_bytes",
                                 "jova_graphconv_workspace_floats", "jova_graphconv_bwd_scratch_floats",

@@ -551,7 +551,7 @@ class JointAttentionFunction(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, n_views, num_heads, num_layers, dprob, training, *args):
+    def forward(ctx, n_views, num_heads, num_layers, dprob, training, attn_hook, *args):
         views = [_c(v) for v in args[:n_views]]
         params = args[n_views:]
         prj = params[:2 * n_views]
@@ -597,6 +597,11 @@ class JointAttentionFunction(torch.autograd.Function):
                  sA=(H * S * Sp, S * Sp), sB=(3 * L, hd), sC=(L, hd))
             xp = _empty((T, L), ref)
             linear_fwd(o, w_o, b_o, xp)
+            if attn_hook is not None:
+                # models.py:952-956: hook(layer, x, x', head-averaged weights [batch, S, S], segments per view); the
+                # weights are what nn.MultiheadAttention returns (after its dropout, averaged over the heads)
+                wts = pd.view(bsz, H, S, Sp)[..., :S].mean(dim=1)
+                attn_hook(len(saved), x.view(S, bsz, L), xp.view(S, bsz, L), wts, list(segs))
             x1 = _empty((T, L), ref)
             mr1 = _empty((T, 2), ref)
             call("jova_layernorm_fwd", P(x), P(xp), P(attn_g), P(attn_b), T, L, 1e-5, P(x1), P(mr1), stream())
@@ -684,14 +689,14 @@ class JointAttentionFunction(torch.autograd.Function):
             dxv = dx[seg_off[v] * bsz: seg_off[v + 1] * bsz]
             xv = views[v].reshape(-1, views[v].shape[2])
             linear_bwd_weight(dxv, xv, tg[2 * v], tg[2 * v + 1])
-            if ctx.needs_input_grad[5 + v]:
+            if ctx.needs_input_grad[6 + v]:
                 gv = _empty(xv.shape, ref)
                 linear_bwd_data(dxv, prj[2 * v], gv)
                 grads_in.append(gv.view(views[v].shape))
             else:
                 grads_in.append(None)
         ctx.saved = None
-        return (None, None, None, None, None) + tuple(grads_in) + tuple(sink.returns)
+        return (None, None, None, None, None, None) + tuple(grads_in) + tuple(sink.returns)
 
 
 class MSELossFunction(torch.autograd.Function):

@@ -214,7 +214,6 @@ class JointAttention(nn.Module):
         super(JointAttention, self).__init__()
         if attn_hook:
             assert callable(attn_hook), "Attention hook must be a function"
-            raise NotImplementedError("attention hooks (explain mode) are outside the training hot path")
         if activation != 'relu':
             raise NotImplementedError("the fused joint-attention path implements the reference's default 'relu'")
         self.attn_hook = attn_hook
@@ -242,7 +241,7 @@ class JointAttention(nn.Module):
                        res.seg_lin.linear2.weight, res.seg_lin.linear2.bias,
                        res.normalize.weight, res.normalize.bias]
         x = F_.JointAttentionFunction.apply(len(inputs), self.num_heads, len(self.attention_models), self.dprob,
-                                            self.training, *(list(inputs) + params))
+                                            self.training, self.attn_hook, *(list(inputs) + params))
         self.batch_norm.fused_relu = True
         try:
             x = self.batch_norm(x)

@@ -60,8 +60,9 @@ def create_prot_net(hparams, model_type, protein_profile):
     raise NotImplementedError("protein view %r is outside the hot path (SURVEY.md section 8)" % model_type)
 
 
-def create_integrated_net(hparams, protein_profile, c_views=("ecfp8", "gconv")):
-    """Same module tree as the reference builder: 0 = NwayForward, 1 = JointAttention, then the FC head."""
+def create_integrated_net(hparams, protein_profile, c_views=("ecfp8", "gconv"), attn_hook=None):
+    """Same module tree as the reference builder: 0 = NwayForward, 1 = JointAttention, then the FC head.
+    ``attn_hook`` is the callback the reference installs in explain mode (train_joint_attn.py:224-227)."""
     creators = {"ecfp8": create_ecfp_net, "gconv": create_gconv_net}
     views, seg_dims = [], []
     for cview in c_views:
@@ -77,13 +78,39 @@ def create_integrated_net(hparams, protein_profile, c_views=("ecfp8", "gconv")):
             seg_dims.append(hparams["prot"]["embedding_dim"])
     layers = [NwayForward(models=views),
               JointAttention(d_dims=seg_dims, latent_dim=hparams["latent_dim"], num_heads=hparams["attn_heads"],
-                             num_layers=hparams["attn_layers"], dprob=hparams["dprob"])]
+                             num_layers=hparams["attn_layers"], dprob=hparams["dprob"], attn_hook=attn_hook)]
     p = len(views) * hparams["latent_dim"]
     for dim in hparams["lin_dims"]:
         layers += [Linear(p, dim), BatchNorm1d(dim), ReLU(), Dropout(hparams["dprob"])]
         p = dim
     layers.append(Linear(in_features=p, out_features=hparams["output_dim"]))
     return nn.Sequential(*layers)
+
+
+def evaluate_model(model, model_dir, model_name, batches, y_std=1.0, y_mean=0.0, device=None):
+    """Jova.evaluate_model (train_joint_attn.py:545-644): load ``<model_dir>/<model_name>`` (a state dict as written by
+    utils.io.save_model), switch to eval mode, run every batch without gradients and take the per-batch metrics on the
+    raw predictions.  Predictions, labels and the metric rows stay on the device until the single copy at the end.
+    Returns dict(metrics=per-metric nanmean, score=mean score, rows=[n_batches, 6], y_pred, y_true) with y_* un-z-scored
+    (undo_transforms, :623-624)."""
+    from .metrics import MetricsLog
+    from .utils import io
+    device = device if device is not None else next(model.parameters()).device
+    model.load_state_dict(io.load_model(model_dir, model_name, dvc=device))
+    model.eval()
+    log = MetricsLog(device, y_std=y_std, y_mean=y_mean)
+    preds, trues = [], []
+    with torch.no_grad():
+        for batch in batches:
+            out = model(batch.model_input())
+            log(out, batch)
+            preds.append(out.reshape(-1).double() * y_std + y_mean)
+            trues.append(batch.y.reshape(-1).double() * y_std + y_mean)
+    summary = log.summary()
+    score = summary.pop("score")
+    return dict(metrics=summary, score=score, rows=log.rows().cpu().numpy(),
+                y_pred=torch.cat(preds).cpu().numpy() if preds else None,
+                y_true=torch.cat(trues).cpu().numpy() if trues else None)
 
 
 def count_parameters(model):
@@ -349,7 +376,7 @@ class Trainer(object):
         ShardSampler epoch).  Per epoch: train phase (model.train(), every batch one ``step``), StepLR.step(), the
         exponential-average guard on the epoch loss (:522-527), then the evaluation phase (model.eval(), no gradients)
         whose mean score selects the best weights (:531-535; kept as a copy of the flat buffer, not a deep-copied state
-        dict).  ``evaluate(outputs, batch) -> device tensor score`` (e.g. metrics.score_on_device); host reads happen
+        dict).  ``evaluate(outputs, batch) -> device tensor score`` (e.g. a metrics.MetricsLog); host reads happen
         once per phase: the non-finite flag, the epoch loss, the mean score.  Returns dict(score, epoch, history)."""
         best = dict(score=-10000.0, epoch=-1)
         best_wts = self.flat.data.clone()
@@ -379,7 +406,7 @@ class Trainer(object):
                     for batch in eval_batches(epoch):
                         outputs = self.model(batch.model_input())
                         scores.append(evaluate(outputs * batch.w, batch).reshape(1))
-                mean_score = float(torch.cat(scores).mean().item()) if scores else float("nan")
+                mean_score = float(torch.cat(scores).double().mean().item()) if scores else float("nan")
                 rec["score"] = mean_score
                 if best["score"] < mean_score:
                     best.update(score=mean_score, epoch=epoch)

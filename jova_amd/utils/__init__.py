@@ -1,0 +1,1 @@
+from . import io  # noqa: F401

@@ -136,9 +136,12 @@ def test_fit_two_epochs_across_a_scheduler_boundary_vs_oracle(device):
                         torch.from_numpy(z["y"][ids]).float().to(device), torch.from_numpy(z["w"][ids]).float().to(device))
     eval_out = []
 
+    from jova_amd.metrics import MetricsLog
+    mlog = MetricsLog(device)
+
     def evaluate(outputs, b):
         eval_out.append(outputs.detach().cpu().double())
-        return -((outputs - b.y) ** 2).mean()
+        return mlog(outputs, b)                                    # device-side rms / ci / r2 / score, no host read
     res = tr.fit(lambda ep: [batch(s) for s in splits], lambda ep: [batch(splits[0])], n_epochs=2, evaluate=evaluate)
 
     # ---- oracle: fp64, torch.optim.SGD + StepLR, BatchNorm running statistics kept by hand for the eval phase
@@ -172,6 +175,11 @@ def test_fit_two_epochs_across_a_scheduler_boundary_vs_oracle(device):
     for h, wl in zip(hist, want_losses):
         assert abs(h["loss"] - wl) <= 2e-5 * abs(wl), (h, wl)
     assert res["epoch"] in (0, 1) and np.isfinite(res["score"]) and len(eval_out) == 2
+    # the evaluation score is Jova.evaluate's (nanmean([ci, r2]) - rms) of that epoch's eval-mode outputs
+    from oracle import metrics_ref as MR
+    want_scores = [MR.dti_metrics(z["y"][splits[0]], o.numpy(), z["w"][splits[0]])[3] for o in eval_out]
+    assert [abs(h["score"] - wsc) < 1e-9 for h, wsc in zip(hist, want_scores)] == [True, True]
+    assert abs(res["score"] - max(want_scores)) < 1e-9 and res["epoch"] == int(np.argmax(want_scores))
     assert not net.training                                        # the loop leaves the model in its last (eval) phase
     # eval-mode outputs are finite and differ between the epochs (the weights moved)
     assert torch.isfinite(eval_out[0]).all() and not torch.equal(eval_out[0], eval_out[1])
