@@ -160,21 +160,26 @@ def graph_stress(device, reps=20, full=True, row_order_lines=True):
     x2 = torch.randn(n, 64, device=device).relu_()
     res = []
 
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_graph.json")) as f:
-            pmc = json.load(f)["kernels"]
-    except (OSError, ValueError, KeyError):
-        pmc = {}
+    pmc = {}
+    for name in ("r01_pmc_graph.json", "r02_pmc_graph.json"):       # later rounds override per kernel
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                pmc.update(json.load(f)["kernels"])
+        except (OSError, ValueError, KeyError):
+            pass
 
     def traffic_of(*kernels):
-        """L2-fabric bytes per launch from the committed PMC passes (profiles/r01_pmc_graph.json), summed over the
+        """L2-fabric bytes per launch from the committed PMC passes (profiles/r0N_pmc_graph.json), summed over the
         kernels of one entry; None when a kernel is missing there."""
         try:
             return int(sum(pmc[k]["traffic_bytes_per_launch"] for k in kernels))
         except KeyError:
             return None
 
-    def timed(name, fn, nbytes, launches=1, kernels=()):
+    def timed(name, fn, nbytes, launches=1, kernels=(), flops=0):
+        """`flops` (the matrix products of the entry, 2 per multiply-add) adds the fp32-MFMA fraction; the entry's
+        `bound` is the roofline that binds (the larger of the two lower bounds on its duration) and `frac` the
+        fraction of THAT one; frac_hbm / frac_mfma are both printed."""
         fn()
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -185,8 +190,15 @@ def graph_stress(device, reps=20, full=True, row_order_lines=True):
         torch.cuda.synchronize()
         ms = a.elapsed_time(b) / reps
         gbs = nbytes / (ms * 1e-3) / 1e9
-        res.append(dict(kernel=name, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(gbs / HBM_PEAK_GBS, 4), us=round(ms * 1e3, 1), algorithmic_bytes=int(nbytes),
+        tfl = flops / (ms * 1e-3) / 1e12
+        frac_hbm, frac_mfma = gbs / HBM_PEAK_GBS, tfl / MFMA_F32_PEAK_TFLOPS
+        mfma_bound = frac_mfma > frac_hbm
+        res.append(dict(kernel=name, bound="mfma" if mfma_bound else "hbm",
+                        achieved=round(tfl if mfma_bound else gbs, 1),
+                        peak=MFMA_F32_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS, unit="TFLOP/s" if mfma_bound else "GB/s",
+                        frac=round(max(frac_hbm, frac_mfma), 4), frac_hbm=round(frac_hbm, 4),
+                        frac_mfma=round(frac_mfma, 4) if flops else None, us=round(ms * 1e3, 1),
+                        algorithmic_bytes=int(nbytes), flops=int(flops) if flops else None,
                         launches=launches, traffic=traffic_of(*kernels) if kernels else None))
 
     def wb(layer):
@@ -208,10 +220,12 @@ def graph_stress(device, reps=20, full=True, row_order_lines=True):
     # per-step kernel reads 4-byte features: algorithmic bytes as SURVEY.md section 8d
     timed("graphconv_fwd_l1(75->64)", lambda: call("jova_graphconv_fwd", P(x1), 0, x1.shape[1], n, 75, 64, ds, adj, pw1,
                                                    pb1, 1, P(out), None, P(ws1), dsh, st),
-          4 * (n * 75 + n * 64 + e) + 4 * 21 * 76 * 64, launches=1, kernels=("graphconv_fwd_wave_kernel<10, 3, false>",))
+          4 * (n * 75 + n * 64 + e) + 4 * 21 * 76 * 64, launches=1, kernels=("graphconv_fwd_wave_kernel<10, 3, false>",),
+          flops=4 * n * 75 * 64)
     timed("graphconv_fwd_l2(64->64)", lambda: call("jova_graphconv_fwd", P(x2), 0, 64, n, 64, 64, ds, adj, pw2, pb2, 1,
                                                    P(out), None, P(ws2), dsh, st),
-          4 * (n * 64 + n * 64 + e) + wbytes, launches=1, kernels=("graphconv_fwd_wave_kernel<8, 4, false>",))
+          4 * (n * 64 + n * 64 + e) + wbytes, launches=1, kernels=("graphconv_fwd_wave_kernel<8, 4, false>",),
+          flops=4 * n * 64 * 64)
     order = P(topo.block_order)
     timed("graphpool_fwd(64)", lambda: call("jova_graphpool_fwd", P(x2), n, 64, ds, adj, P(out), P(arg), order, st),
           4 * (2 * n * 64 + e) + n * 64, kernels=("graphpool_fwd_v4_kernel",))
@@ -234,12 +248,15 @@ def graph_stress(device, reps=20, full=True, row_order_lines=True):
               lambda: call("jova_graphconv_bwd", P(x1), 0, x1.shape[1], n, 75, 64, ds, adj, pw1, P(dz), None, pdw1, pdb1,
                            None, None, P(topo.sym_flag), dsh, P(dws), None, st),
               4 * (n * 64 + n * 75 + e) + 2 * 4 * 21 * 76 * 64,
-              kernels=("graphconv_bwd_dma_kernel<10, false, false, 4, false>", "graphconv_dw_fold_kernel"), launches=3)
-        timed("graphconv_bwd_l2(dW + dX, 2 launches)",
+              kernels=("graphconv_bwd_dma_kernel<10, false, false, 4, false>", "graphconv_dw_fold_kernel"), launches=3,
+              flops=4 * n * 75 * 64)
+        # 64 -> 64: graphconv_bwd_wave_kernel (dW_self, dW_rel, G = dZ W_rel) + graphconv_bwd_dx_wave_kernel
+        # (dx = dZ W_self + gathered G) + the scatter kernel that returns at once on a bond graph
+        timed("graphconv_bwd_l2(dW + dX, 3 launches)",
               lambda: call("jova_graphconv_bwd", P(x2), 0, 64, n, 64, 64, ds, adj, pw2, P(dz), None, pdw2, pdb2, P(dx),
                            P(gbuf), P(topo.sym_flag), dsh, None, order, st),
-              4 * (n * 64 + 3 * n * 64 + e) + 2 * wbytes, launches=2,
-              kernels=("graphconv_bwd_dma_kernel<8, true, false, 4, false>", "graphconv_bwd_dx_v4_kernel"))
+              4 * (n * 64 + 3 * n * 64 + e) + 2 * wbytes, launches=3, flops=8 * n * 64 * 64,
+              kernels=("graphconv_bwd_wave_kernel<8, true, 2>", "graphconv_bwd_dx_wave_kernel"))
         timed("graphpool_bwd(64)", lambda: call("jova_graphpool_bwd", P(dz), P(arg), n, 64, ds, adj, P(dx),
                                                 P(topo.sym_flag), sym, P(topo.rev_pos), order, st),
               4 * (2 * n * 64 + e) + n * 64, kernels=("graphpool_bwd_v5_kernel",))
@@ -271,8 +288,9 @@ def graph_stress(device, reps=20, full=True, row_order_lines=True):
               lambda: call("jova_nonsat_fwd", P(og), ne, 1e-4, 100, P(on), P(df), P(nev), P(wsn), st),
               ne * (12 * evals + 16), launches=3, kernels=("nonsat_persistent_kernel<4>",))
     return dict(workload="graph4k: 4096 molecules, %d atoms, %d directed edges" % (n, e), kernels=res,
-                note="kernel durations: reps launches through the C ABI between two HIP events; fwd = weight re-pack + "
-                     "kernel; conv backward takes dZ (ReLU mask applied by the BatchNorm backward, as in the model)")
+                note="kernel durations: reps launches through the C ABI between two HIP events; conv backward takes dZ "
+                     "(ReLU mask applied by the BatchNorm backward, as in the model); frac_mfma against the dense fp32 "
+                     "matrix peak (157.3 TFLOP/s), frac_hbm against 8 TB/s, frac = the binding one")
 
 
 def main():

@@ -1835,6 +1835,10 @@ struct WavePlan {
 __device__ __forceinline__ void dma16_m0(const float* g, unsigned lds) {        // lds: wave-uniform LDS byte address
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds) : "memory", "m0");
 }
+// the same with a wave-uniform base pointer (SGPR pair) and a 32-bit per-lane byte offset: no 64-bit address registers
+__device__ __forceinline__ void dma16_m0_s(const float* base, unsigned off, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory", "m0");
+}
 __device__ __forceinline__ unsigned lds_byte_addr(const float* p) {
     return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) float*)p);
 }
@@ -2227,6 +2231,596 @@ graphconv_fwd_wave_kernel(const float* __restrict__ x, int n_atoms, int ldx, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, wave-private form
+// The forward's organisation (a wave owns 16-atom tiles, rows by LDS-DMA into wave-owned planes, no workgroup barrier
+// in the loop, the memory traffic of the neighbouring tiles issued in the MFMA shadow) applied to the backward with dZ
+// handed in (the consumer applied the ReLU mask).  Per tile, on v_mfma_f32_16x16x4_f32:
+//   phase A (only with dx):  [G | T]^T = [W_rel | W_self]^T dZ^T      128 MFMAs; the transposed weights sit in LDS in
+//            fragment order (A operand), dZ is the B operand read atom-major as in the forward, so a lane ends with four
+//            consecutive input features of one atom: 16-byte stores.  G -> gbuf (read by the neighbours in
+//            graphconv_bwd_dx_v4_kernel), T -> dx.
+//   phase B: dW_self += dZ^T X, dW_rel += dZ^T S                      2 x 16 x (f_in / 16) MFMAs; both operands are read
+//            from the planes "transposed" (lane = (column, atom quad): one ds_read_b32 per fragment register), the
+//            neighbour sum S is formed while reading.  The 2 x 64 x f_in accumulators (128 / 160 registers) stay in the
+//            wave for all its tiles: a workgroup works on ONE degree bucket (WavePlan), so there is one reduction over
+//            the eight waves (through the then idle planes) and one atomic per weight element and workgroup at the end.
+// The planes are free once phase B's fragments are in registers: the next tile's DMA (own rows, neighbours, dZ) is
+// issued between phase B's MFMA groups, the stores of G in phase A's second half, those of T in phase B.
+template <int KG, bool DX, int NBR>
+__global__ void __launch_bounds__(512, 1)
+graphconv_bwd_wave_kernel(const float* __restrict__ x, int n_atoms, int ldx, int f_in, GcParams P,
+                          const float* __restrict__ dz, GcGrads Gd, float* __restrict__ gbuf, float* __restrict__ dx,
+                          float* __restrict__ dwp, WavePlan plan) {
+    constexpr int NFB = KG / 2;                      // 16-feature blocks of the input rows
+    constexpr int NPL = 1 + NBR;                     // x planes: own rows + NBR neighbour planes per gather round
+    constexpr int PPP = KG > 8 ? 5 : 4;              // DMA pieces per x plane
+    constexpr int NPC = NPL * PPP + 4;               // ... per tile (the dZ plane has four)
+    constexpr int TAIL_F = KG > 8 ? WT * 16 : 0;
+    constexpr int PLANE_F = WT * 64 + TAIL_F;
+    constexpr int WAVE_F = NPL * PLANE_F + WT * 64;  // floats of a wave's planes (x planes, then the dZ plane)
+    constexpr int WMAT_F = DX ? 4 * 4 * 256 : 0;     // the transposed W_rel image [fb][m][lane][s]
+    constexpr int ACC_F = 16 * NFB * 64;             // floats of one wave's accumulator image of ONE weight matrix
+    static_assert(PPP + 4 <= 12 && NBR * PPP <= 15, "every DMA piece of a tile needs a side slot in phase B");
+    static_assert(4 * ACC_F + 8 * 64 <= 8 * WAVE_F, "the reduction image must fit in the planes");
+    static_assert(!DX || KG == 8, "dx is produced for 64-float rows");
+    __shared__ __attribute__((aligned(16))) float lds[WMAT_F + 8 * WAVE_F];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 15, q = lane >> 4;
+#ifdef JOVA_WAVE_PROFILE
+    const unsigned long long pw_entry = wall_clock64();
+#endif
+
+    // ---- this workgroup's bucket and its chunk of the bucket's tiles (as in the forward)
+    int kb = 0;
+#pragma unroll
+    for (int k = 1; k < NB; ++k) kb += ((int)blockIdx.x >= plan.first[k]) ? 1 : 0;
+    const int deg = NB - 1 - kb;
+    const int wg0 = plan.first[kb], nwg = plan.first[kb + 1] - wg0;
+    int bstart = 0, bsize = 0;
+#pragma unroll
+    for (int d = 0; d < NB; ++d) {
+        if (d == deg) { bstart = plan.start[d]; bsize = plan.size[d]; }
+    }
+    int chunk = 0;
+    {
+        const int xcd = blockIdx.x & 7, j = (int)blockIdx.x - wg0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j0 = (k - wg0) & 7;
+            const int cnt = j0 < nwg ? (nwg - j0 + 7) >> 3 : 0;
+            chunk += k < xcd ? cnt : 0;
+        }
+        chunk += (j - ((xcd - wg0) & 7)) >> 3;
+    }
+    const int tiles = (bsize + WT - 1) / WT;
+    const int per = (tiles + nwg - 1) / nwg;
+    const int t_begin = chunk * per, t_end = min(tiles, t_begin + per);
+    const int t0 = t_begin + wave;
+
+    float* const pl = lds + WMAT_F + wave * WAVE_F;
+    float* const zpl = pl + NPL * PLANE_F;
+    const unsigned pl_addr = lds_byte_addr(pl);
+    const int* adj_d = deg > 0 ? P.adj[deg - 1] : nullptr;
+    const unsigned nmax = (unsigned)(n_atoms - 1);
+    const int cnt0 = min(deg, NBR);
+
+    int ix[NBR][4];
+    int ixt[KG > 8 ? NBR : 1];
+    auto load_idx = [&](int t, int nb0) {
+        const int lrow0 = t * WT, rows = min(WT, bsize - lrow0);
+#pragma unroll
+        for (int p = 0; p < NBR; ++p) {
+            if (nb0 + p < deg) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = min(4 * j + q, rows - 1);
+                    ix[p][j] = adj_d[(unsigned)((lrow0 + r) * deg + nb0 + p)];
+                }
+                if (KG > 8) {
+                    const int r = min(lane >> 2, rows - 1);
+                    ixt[p] = adj_d[(unsigned)((lrow0 + r) * deg + nb0 + p)];
+                }
+            }
+        }
+    };
+    // (32-bit byte offsets from the uniform base pointers: the host checks n_atoms * ldx * 4 < 2^32)
+    const unsigned ldx4 = (unsigned)ldx * 4u;
+    const unsigned ch16 = (unsigned)(((lane & 15) ^ q) << 4);          // byte offset of chunk (lane & 15) ^ q
+    const unsigned cht = 256u + (unsigned)((((lane & 3) ^ ((4 - (lane >> 4)) & 3))) << 4);
+    auto issue_piece = [&](int pp, int j, int row) {            // x plane pp, piece j
+        if (j < 4) {
+            // row 4 j + q takes chunk (lane & 15) ^ (4 j + q) = ((lane & 15) ^ q) ^ 4 j
+            dma16_m0_s(x, min((unsigned)row, nmax) * ldx4 + (ch16 ^ (unsigned)(j << 6)), pl_addr + (pp * PLANE_F + j * 256) * 4);
+        } else {
+            dma16_m0_s(x, min((unsigned)row, nmax) * ldx4 + cht, pl_addr + (pp * PLANE_F + WT * 64) * 4);
+        }
+    };
+    // piece k of the first gather round of tile t: x planes first, then the four pieces of the dZ plane
+    auto issue_round0_piece = [&](int t, int k) {
+        const int lrow0 = t * WT, rows = min(WT, bsize - lrow0);
+        if (k >= NPL * PPP) {
+            const int j = k - NPL * PPP;
+            const unsigned row = (unsigned)(bstart + lrow0 + min(4 * j + q, rows - 1));
+            dma16_m0_s(dz, min(row, nmax) * 256u + (ch16 ^ (unsigned)(j << 6)), pl_addr + (NPL * PLANE_F + j * 256) * 4);
+            return;
+        }
+        const int pp = k / PPP, j = k % PPP;
+        if (pp > cnt0) return;
+        int row;
+        if (pp == 0) row = bstart + lrow0 + min(j < 4 ? 4 * j + q : lane >> 2, rows - 1);
+        else row = j < 4 ? ix[pp - 1 < NBR ? pp - 1 : 0][j < 4 ? j : 0] : ixt[KG > 8 ? (pp - 1 < NBR ? pp - 1 : 0) : 0];
+        issue_piece(pp, j, row);
+    };
+    // "transposed" fragments of a plane: f[fb][ks] = plane[atom 4 ks + q][feature 16 fb + i]
+    // (main image: chunk c = 4 fb + (i >> 2) of row r = 4 ks + q sits at position c ^ r = 4 (fb ^ ks) + ((i >> 2) ^ q):
+    //  ONE lane-dependent offset, everything else is an instruction immediate)
+    const int tsw = (i >> 2);
+    const int lane_t = q * 64 + ((tsw ^ q) << 2) + (i & 3);
+    const int lane_tt = q * 16 + (i & 3);
+    auto read_plane_t = [&](const float* b, float (&f)[NFB][4], bool add) {
+        const float* bl = b + lane_t;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) {
+                float v;
+                if (fb < 4) v = bl[ks * 256 + ((fb ^ ks) << 4)];
+                else v = b[WT * 64 + ks * 64 + lane_tt + ((tsw ^ ((4 - ks) & 3)) << 2)];
+                f[fb][ks] = add ? f[fb][ks] + v : v;
+            }
+            // (adding a plane: one atom quad at a time, so that only NFB loaded values wait for their add)
+            if (add) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- prologue: weight loads, the first tile's indices and its index-free pieces (own rows, dZ) leave together; the
+    // neighbours' pieces follow as soon as the indices are here (in-order counter: everything but the PPP + 4 pieces)
+    int tc = t0, tn = t0 + 8, tn2 = 0;
+    const int w_rel = deg > 0 ? 2 * (deg - 1) : 20, w_self = deg == 0 ? 20 : 2 * (deg - 1) + 1;
+    float4 wv[2];
+    if (DX && deg > 0) {
+        // image[fb][m][lane][s] = W_rel[16 m + 4 (lane >> 4) + s][16 fb + (lane & 15)]
+        const float* W = P.w[w_rel];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int o = tid + 512 * e;
+            const int ln = o & 63, fm = o >> 6;
+            const int row = 16 * (fm & 3) + 4 * (ln >> 4), col = 16 * (fm >> 2) + (ln & 15);
+            wv[e] = make_float4(W[(row + 0) * f_in + col], W[(row + 1) * f_in + col], W[(row + 2) * f_in + col],
+                                W[(row + 3) * f_in + col]);
+        }
+    }
+    if (tc < t_end) {
+        if (deg > 0) load_idx(tc, 0);
+#pragma unroll
+        for (int k = 0; k < PPP; ++k) issue_round0_piece(tc, k);
+#pragma unroll
+        for (int k = NPL * PPP; k < NPC; ++k) issue_round0_piece(tc, k);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (PPP + 4));
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = PPP; k < NPL * PPP; ++k) issue_round0_piece(tc, k);
+        if (deg > 0 && tn < t_end) load_idx(tn, 0);
+    }
+    if (DX && deg > 0) {
+        float4* d0 = reinterpret_cast<float4*>(lds);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) d0[tid + 512 * e] = wv[e];
+    }
+    __syncthreads();
+    tn2 = tn + 8;
+    if (wave >= 4 && JOVA_WAVE_STAGGER > 0) __builtin_amdgcn_s_sleep(JOVA_WAVE_STAGGER);
+
+    f32x4v accS[4][NFB], accR[4][NFB];               // dW_self / dW_rel [16 nb + 4 q + r][16 fb + i]
+    float dbacc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        dbacc[nb] = 0.f;
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) accS[nb][fb] = accR[nb][fb] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    }
+    const float* wl0 = lds + lane * 4;               // W_rel^T image
+#ifdef JOVA_WAVE_PROFILE
+    unsigned long long pf[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long pw_loop = wall_clock64();
+    const unsigned long long pf_start = __builtin_readcyclecounter();
+    int n_done = 0;
+#endif
+
+    for (; tc < t_end; tc = tn, tn = tn2, tn2 += 8) {
+        const int t = tc;
+        const int lrow0 = t * WT, rows = min(WT, bsize - lrow0);
+        WPROF(p0);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // this tile's planes landed
+        asm volatile("" ::: "memory");
+        WPROF(p1);
+        f32x4v accG[4];
+        float* grow = nullptr;
+        if (DX && deg > 0) {
+            // ---- phase A: G^T = W_rel^T dZ^T (the neighbours' share of dx; the own share T = dZ W_self is formed by
+            // graphconv_bwd_dx_wave_kernel, which is memory-bound and has the matrix pipe to spare)
+            f32x4v zf[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) zf[m] = *reinterpret_cast<const f32x4v*>(zpl + i * 64 + (((4 * m + q) ^ i) << 2));
+            grow = gbuf + (size_t)(bstart + lrow0 + min(i, rows - 1)) * 64 + 4 * q;
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb) accG[fb] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+            f32x4v w[2][4];
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb) w[0][fb] = *reinterpret_cast<const f32x4v*>(wl0 + (fb * 4) * 256);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int c = m & 1, nx = c ^ 1;
+                if (m + 1 < 4) {
+#pragma unroll
+                    for (int fb = 0; fb < 4; ++fb)
+                        w[nx][fb] = *reinterpret_cast<const f32x4v*>(wl0 + (fb * 4 + m + 1) * 256);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int fb = 0; fb < 4; ++fb)
+                        accG[fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c][fb][s], zf[m][s], accG[fb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+#ifdef JOVA_WAVE_PROFILE
+        if (DX && deg > 0) asm volatile("s_nop 0" ::"v"(accG[0]), "v"(accG[1]), "v"(accG[2]), "v"(accG[3]));
+#endif
+        WPROF(p2);
+        // ---- phase B1: dW_self += dZ^T X.  Once dZ^T and X^T are in registers the own plane and the dZ plane are free:
+        // the next tile's pieces for them are issued between the MFMA groups, then T's four stores.
+        float zt[4][4], xs[NFB][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bool live = 4 * ks + q < rows;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const float v = zpl[lane_t + ks * 256 + ((nb ^ ks) << 4)];
+                zt[nb][ks] = live ? v : 0.f;             // rows past the bucket's end repeat its last row: no contribution
+            }
+        }
+        read_plane_t(pl, xs, false);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) dbacc[nb] += (zt[nb][0] + zt[nb][1]) + (zt[nb][2] + zt[nb][3]);
+        WPROF(p3);
+        const bool nxt = tn < t_end;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int k = 4 * ks + nb;
+                if (k < PPP) { if (nxt) issue_round0_piece(tn, k); }                         // own plane
+                else if (k < PPP + 4) { if (nxt) issue_round0_piece(tn, NPL * PPP + k - PPP); }   // dZ plane
+                else if (DX && k >= 12 && grow != nullptr) *reinterpret_cast<f32x4v*>(grow + 16 * (k - 12)) = accG[k - 12];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb)
+                    accS[nb][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[nb][ks], xs[fb][ks], accS[nb][fb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#ifdef JOVA_WAVE_PROFILE
+        asm volatile("s_nop 0" ::"v"(accS[3][NFB - 1]));
+        const unsigned long long p4 = __builtin_readcyclecounter();
+        pf[0] += p1 - p0; pf[1] += p2 - p1; pf[2] += p3 - p2; pf[3] += p4 - p3;
+        ++n_done;
+#endif
+        if (deg == 0) continue;                      // (workgroup-uniform)
+
+        // ---- phase B2: dW_rel += dZ^T S, S = sum of the neighbour rows (formed while reading, plane by plane)
+        float xn[NFB][4];
+        read_plane_t(pl + PLANE_F, xn, false);
+        if (NBR > 1 && deg > 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            read_plane_t(pl + (NBR > 1 ? 2 : 1) * PLANE_F, xn, true);
+        }
+        for (int nb0 = NBR; nb0 < deg; nb0 += NBR) {               // further gather rounds of a high-degree tile
+            load_idx(t, nb0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the planes' previous contents have been read
+#pragma unroll
+            for (int p = 0; p < NBR; ++p) {
+                if (nb0 + p < deg) {
+#pragma unroll
+                    for (int j = 0; j < PPP; ++j) issue_piece(1 + p, j, j < 4 ? ix[p][j < 4 ? j : 0] : ixt[KG > 8 ? p : 0]);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int p = 0; p < NBR; ++p) {
+                if (nb0 + p < deg) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_plane_t(pl + (1 + p) * PLANE_F, xn, true);
+                }
+            }
+            if (nb0 + NBR >= deg && tn < t_end) load_idx(tn, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every fragment of this tile is in registers
+        WPROF(p5);
+        const bool nxt2 = tn2 < t_end && deg <= NBR;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const int k = 4 * ks + nb;
+                if (k < NBR * PPP) { if (nxt) issue_round0_piece(tn, PPP + k); }            // neighbour planes
+                if (k == 15 && nxt2) load_idx(tn2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb)
+                    accR[nb][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[nb][ks], xn[fb][ks], accR[nb][fb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#ifdef JOVA_WAVE_PROFILE
+        asm volatile("s_nop 0" ::"v"(accR[3][NFB - 1]));
+        const unsigned long long p6 = __builtin_readcyclecounter();
+        pf[4] += p5 - p4; pf[5] += p6 - p5;
+#endif
+    }
+#ifdef JOVA_WAVE_PROFILE
+    if (lane == 0 && blockIdx.x < 256) {
+        unsigned long long* o = g_wave_prof + (blockIdx.x * 8 + wave) * 8;
+        o[0] = pf[0]; o[1] = pf[1]; o[2] = pf[2]; o[3] = pf[3]; o[4] = pf[4];
+        o[5] = pf[5]; o[6] = n_done; o[7] = deg;
+    }
+    const unsigned long long pw_end = wall_clock64();
+#endif
+
+    // ---- reduction over the eight waves (through the planes), then one atomic per weight element and workgroup
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    float* const red = lds + WMAT_F;                 // [4 waves][ACC_F], then [8 waves][64] column sums of dZ
+    float* const dbred = red + 4 * ACC_F;
+    float* const ws = dwp ? dwp + (long long)w_self * 64 * DWP_LD : Gd.dw[w_self];
+    float* const wr = dwp ? dwp + (long long)w_rel * 64 * DWP_LD : Gd.dw[w_rel];
+    const int ldw = dwp ? DWP_LD : f_in;
+#pragma unroll
+    for (int mat = 0; mat < 2; ++mat) {
+        if (mat == 1 && deg == 0) break;             // (workgroup-uniform)
+        f32x4v (&acc)[4][NFB] = mat == 0 ? accS : accR;
+        __syncthreads();                             // the planes (or the previous matrix's image) are idle
+        if (wave >= 4) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb)
+                    *reinterpret_cast<f32x4v*>(red + (wave - 4) * ACC_F + ((nb * NFB + fb) * 64 + lane) * 4) = acc[nb][fb];
+        }
+        __syncthreads();
+        if (wave < 4) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) {
+                    f32x4v* p = reinterpret_cast<f32x4v*>(red + wave * ACC_F + ((nb * NFB + fb) * 64 + lane) * 4);
+                    *p = *p + acc[nb][fb];
+                }
+        }
+        if (mat == 0) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                float s = dbacc[nb];
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                if (q == 0) dbred[wave * 64 + 16 * nb + i] = s;
+            }
+        }
+        __syncthreads();
+        float* const dst = mat == 0 ? ws : wr;
+        for (int e = tid; e < ACC_F / 4; e += 512) {
+            // float4 e of the image: (nb, fb) = e / 64, lane' = e % 64 -> rows o = 16 nb + 4 q' + r, column 16 fb + i'
+            const float4 a = *reinterpret_cast<const float4*>(red + 4 * e);
+            const float4 b = *reinterpret_cast<const float4*>(red + ACC_F + 4 * e);
+            const float4 c = *reinterpret_cast<const float4*>(red + 2 * ACC_F + 4 * e);
+            const float4 d = *reinterpret_cast<const float4*>(red + 3 * ACC_F + 4 * e);
+            const int ln = e & 63, bf = e >> 6;
+            const int o = 16 * (bf / NFB) + 4 * (ln >> 4), k = 16 * (bf % NFB) + (ln & 15);
+            if (k < f_in) {
+                atomicAdd(&dst[(o + 0) * ldw + k], (a.x + b.x) + (c.x + d.x));
+                atomicAdd(&dst[(o + 1) * ldw + k], (a.y + b.y) + (c.y + d.y));
+                atomicAdd(&dst[(o + 2) * ldw + k], (a.z + b.z) + (c.z + d.z));
+                atomicAdd(&dst[(o + 3) * ldw + k], (a.w + b.w) + (c.w + d.w));
+            }
+        }
+        if (mat == 0 && tid < 64) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += dbred[w * 64 + tid];
+            atomicAdd(&Gd.db[w_self][tid], s);
+            if (deg > 0) atomicAdd(&Gd.db[w_rel][tid], s);
+        }
+    }
+#ifdef JOVA_WAVE_PROFILE
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (lane == 0 && blockIdx.x < 256 && wave == 0) {
+        unsigned long long* o = g_wave_prof + 256 * 64 + blockIdx.x * 2;
+        o[0] = (pw_entry & 0xFFFFFFFFull) | ((pw_loop & 0xFFFFFFFFull) << 32);
+        o[1] = (pw_end & 0xFFFFFFFFull) | ((wall_clock64() & 0xFFFFFFFFull) << 32);
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------ dx of the wave-private backward
+// dx[a] = dZ[a] W_self[deg(a)]  +  sum over a's neighbours n of G[n]      (G = dZ W_rel from graphconv_bwd_wave_kernel)
+// Memory-bound (reads dZ and the gathered G rows, writes dx), so the 64 MFMAs per 16-atom tile of the own share ride
+// along for free and T never exists in memory.  A wave owns a tile: dZ fragments and the neighbours' G rows come
+// straight into registers (a lane holds four consecutive features of one atom, as in the forward's epilogue), many
+// small workgroups (one degree bucket each, its transposed W_self in LDS) hide the gather latency by occupancy.
+// Asymmetric adjacency (*sym_flag == 0): only the own share is written here, graphconv_bwd_dx_scatter_kernel adds the
+// rest with float atomics.
+__global__ void __launch_bounds__(256, 4)
+graphconv_bwd_dx_wave_kernel(const float* __restrict__ dz, int n_atoms, GcParams P, const float* __restrict__ gbuf,
+                             float* __restrict__ dx, const int* __restrict__ sym_flag, WavePlan plan, int tpw) {
+    __shared__ __attribute__((aligned(16))) float wimg[4 * 4 * 256];
+    __shared__ __attribute__((aligned(16))) float tile[4][WT * 64];       // per wave: the dZ tile, then the T tile
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 15, q = lane >> 4;
+    int kb = 0;
+#pragma unroll
+    for (int k = 1; k < NB; ++k) kb += ((int)blockIdx.x >= plan.first[k]) ? 1 : 0;
+    const int deg = NB - 1 - kb;
+    int bstart = 0, bsize = 0;
+#pragma unroll
+    for (int d = 0; d < NB; ++d) {
+        if (d == deg) { bstart = plan.start[d]; bsize = plan.size[d]; }
+    }
+    const int tiles = (bsize + WT - 1) / WT;
+    const int t_first = ((int)blockIdx.x - plan.first[kb]) * 4 * tpw;
+    const int t_last = min(tiles, t_first + 4 * tpw);
+    const int* adj_d = deg > 0 ? P.adj[deg - 1] : nullptr;
+    const unsigned nmax = (unsigned)(n_atoms - 1);
+    float* const tl = tile[wave];
+    const unsigned tl_addr = lds_byte_addr(tl);
+    const unsigned ch16 = (unsigned)(((lane & 15) ^ q) << 4);
+    // the wave's first dZ tile travels while the weights are staged
+    auto issue_z = [&](int t) {
+        const int lrow0 = t * WT, rows = min(WT, bsize - lrow0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned row = (unsigned)(bstart + lrow0 + min(4 * j + q, rows - 1));
+            dma16_m0_s(dz, min(row, nmax) * 256u + (ch16 ^ (unsigned)(j << 6)), tl_addr + j * 1024);
+        }
+    };
+    const int np = *sym_flag != 0 ? deg : 0;
+    // indices of a tile in the gather layout: lane -> atom 4 j + q (j = 0..3), 16-byte chunk i of its row
+    unsigned nb0[4], nb1[4];
+    auto load_nb = [&](int t) {
+        const int lrow0 = t * WT, rows = min(WT, bsize - lrow0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lr = lrow0 + min(4 * j + q, rows - 1);
+            nb0[j] = nb1[j] = 0;
+            if (np > 0) nb0[j] = (unsigned)adj_d[(unsigned)(lr * deg)];
+            if (np > 1) nb1[j] = (unsigned)adj_d[(unsigned)(lr * deg + 1)];
+        }
+    };
+    // the wave's first dZ tile and its first indices travel while the weights are staged
+    if (t_first + wave < t_last) {
+        issue_z(t_first + wave);
+        load_nb(t_first + wave);
+    }
+    {
+        // image[fb][m][lane][s] = W_self[16 m + 4 (lane >> 4) + s][16 fb + (lane & 15)]
+        const float* W = P.w[deg == 0 ? 20 : 2 * (deg - 1) + 1];
+        float4 v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int o = tid + 256 * e;
+            const int ln = o & 63, fm = o >> 6;
+            const int row = 16 * (fm & 3) + 4 * (ln >> 4), col = 16 * (fm >> 2) + (ln & 15);
+            v[e] = make_float4(W[(row + 0) * 64 + col], W[(row + 1) * 64 + col], W[(row + 2) * 64 + col], W[(row + 3) * 64 + col]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) reinterpret_cast<float4*>(wimg)[tid + 256 * e] = v[e];
+    }
+    __syncthreads();
+    const float* wl = wimg + lane * 4;
+    bool first = true;
+    for (int t = t_first + wave; t < t_last; t += 4) {
+        const int lrow0 = t * WT, rows = min(WT, bsize - lrow0);
+        int lr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lr[j] = lrow0 + min(4 * j + q, rows - 1);
+        // this tile's dZ and indices were requested in front of the previous tile's four stores: those may still travel
+        asm volatile("" ::: "memory");
+        if (first) __builtin_amdgcn_s_waitcnt(0x0F70);
+        else __builtin_amdgcn_s_waitcnt(0x0F74);
+        asm volatile("" ::: "memory");
+        first = false;
+        // the neighbours' G rows of the first two list positions travel during the MFMAs
+        f32x4v g0[4], g1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            g0[j] = g1[j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+            if (np > 0) g0[j] = *reinterpret_cast<const f32x4v*>(gbuf + (size_t)min(nb0[j], nmax) * 64 + 4 * i);
+            if (np > 1) g1[j] = *reinterpret_cast<const f32x4v*>(gbuf + (size_t)min(nb1[j], nmax) * 64 + 4 * i);
+        }
+        f32x4v zf[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) zf[m] = *reinterpret_cast<const f32x4v*>(tl + i * 64 + (((4 * m + q) ^ i) << 2));
+        f32x4v acc[4];
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) acc[fb] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        f32x4v w[2][4];
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) w[0][fb] = *reinterpret_cast<const f32x4v*>(wl + (fb * 4) * 256);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int c = m & 1, nx = c ^ 1;
+            if (m + 1 < 4) {
+#pragma unroll
+                for (int fb = 0; fb < 4; ++fb) w[nx][fb] = *reinterpret_cast<const f32x4v*>(wl + (fb * 4 + m + 1) * 256);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int fb = 0; fb < 4; ++fb)
+                    acc[fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c][fb][s], zf[m][s], acc[fb], 0, 0, 0);
+            }
+        }
+        // T^T (lane: atom i, features 16 fb + 4 q ..) -> the tile (chunk c of row r at position c ^ r) -> row-major lanes
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) *reinterpret_cast<f32x4v*>(tl + i * 64 + (((4 * fb + q) ^ i) << 2)) = acc[fb];
+        f32x4v o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = *reinterpret_cast<const f32x4v*>(tl + (4 * j + q) * 64 + ((i ^ (4 * j + q)) << 2));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += g0[j] + g1[j];
+        for (int p = 2; p < np; p += 2) {                          // further neighbours, two rows in flight
+            const bool two = p + 1 < np;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                nb0[j] = (unsigned)adj_d[(unsigned)(lr[j] * deg + p)];
+                nb1[j] = two ? (unsigned)adj_d[(unsigned)(lr[j] * deg + p + 1)] : nb0[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                g0[j] = *reinterpret_cast<const f32x4v*>(gbuf + (size_t)min(nb0[j], nmax) * 64 + 4 * i);
+                g1[j] = *reinterpret_cast<const f32x4v*>(gbuf + (size_t)min(nb1[j], nmax) * 64 + 4 * i);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += two ? g0[j] + g1[j] : g0[j];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the tile's T has been read: the plane is free
+        if (t + 4 < t_last) {
+            issue_z(t + 4);
+            load_nb(t + 4);
+        }
+        asm volatile("" ::: "memory");
+        // (rows past the bucket's end repeat its last row: same values to the same address)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4v*>(dx + (size_t)(bstart + lr[j]) * 64 + 4 * i) = o[j];
+        asm volatile("" ::: "memory");
+    }
+}
+
+// asymmetric adjacency only: dx[n] += G[a] for every neighbour n of a (float atomics); returns at once otherwise
+__global__ void __launch_bounds__(256)
+graphconv_bwd_dx_scatter_kernel(int n_atoms, const long long* __restrict__ deg_slice, GcParams P,
+                                const float* __restrict__ gbuf, float* __restrict__ dx, const int* __restrict__ sym_flag) {
+    if (*sym_flag != 0) return;
+    const int l16 = threadIdx.x & 15;
+    for (long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); row < n_atoms; row += (long long)gridDim.x * 16) {
+        int deg;
+        long long lrow;
+        find_bucket(deg_slice, row, deg, lrow);
+        if (deg == 0) continue;
+        const int* arow = P.adj[deg - 1] + lrow * deg;
+        const float4 g = *reinterpret_cast<const float4*>(gbuf + row * 64 + 4 * l16);
+        for (int n = 0; n < deg; ++n) {
+            float* d = dx + (long long)min(max(arow[n], 0), n_atoms - 1) * 64 + 4 * l16;
+            atomicAdd(d, g.x); atomicAdd(d + 1, g.y); atomicAdd(d + 2, g.z); atomicAdd(d + 3, g.w);
+        }
+    }
+}
+
 // ================================================================================================ C ABI
 static int g_num_cu = 0;
 static hipError_t num_cu_cached() {
@@ -2292,7 +2886,7 @@ static int make_plan(const int64_t* dsh, int64_t n_atoms, int nbp, int slots_per
 
 // Work split of the wave-private forward: workgroups per bucket in proportion to its cost (a tile of degree d costs
 // one MFMA phase -- about half of one for d = 0 -- plus a share per extra gather round), <= num_wg workgroups in all.
-static int make_wave_plan(const int64_t* dsh, int64_t n_atoms, int nbr, int num_wg, WavePlan& plan) {
+static int make_wave_plan(const int64_t* dsh, int64_t n_atoms, int nbr, int num_wg, WavePlan& plan, bool bwd = false) {
     memset(&plan, 0, sizeof(plan));
     double cost[NB], total = 0.0;
     for (int d = 0; d < NB; ++d) {
@@ -2307,7 +2901,9 @@ static int make_wave_plan(const int64_t* dsh, int64_t n_atoms, int nbr, int num_
         // (tools/prof_wave.py): the MFMA phase is the same for every degree >= 1, the gather rounds are not
         static const double rel3[NB] = {0.6, 1.0, 1.08, 1.18, 1.40, 1.46, 1.54, 1.78, 1.82, 1.90, 2.15};
         static const double rel2[NB] = {0.6, 1.0, 1.08, 1.35, 1.45, 1.70, 1.80, 2.05, 2.15, 2.40, 2.50};
-        cost[d] = (double)((sz + WT - 1) / WT) * (nbr >= 3 ? rel3[d] : rel2[d]);
+        // backward (two neighbour planes, G + dW phases; tools/prof_wave_bwd.py)
+        static const double relb[NB] = {0.45, 1.0, 1.08, 1.39, 1.47, 1.71, 1.77, 1.99, 2.06, 2.30, 2.36};
+        cost[d] = (double)((sz + WT - 1) / WT) * (bwd ? relb[d] : nbr >= 3 ? rel3[d] : rel2[d]);
         total += cost[d];
     }
     if (total <= 0.0) return 0;
@@ -2480,6 +3076,61 @@ extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t l
     if (!atoms_is_i64 && f_out == 64 && (kg == 8 || kg == 10) && ld_atoms >= 8 * kg && (ld_atoms & 3) == 0 && al16 &&
         n_atoms < (1 << 24) && n_atoms * ld_atoms < (1ll << 31) &&
         (!dx_or_null || (kg == 8 && (f_in & 3) == 0)) && !getenv("JOVA_GRAPHCONV_NO_DMA")) {
+        // weight rows that are not whole 128-byte lines: accumulate in the aligned scratch image, fold afterwards
+        float* dwp = (dw_scratch_or_null && (f_in & 31) != 0 && !getenv("JOVA_BWD_NO_DWP")) ? dw_scratch_or_null : nullptr;
+        if (dwp) JOVA_CHECK_HIP(hipMemsetAsync(dwp, 0, sizeof(float) * 21 * 64 * DWP_LD, s));
+        // wave-private form (see graphconv_bwd_wave_kernel): dZ handed in, host copy of the bucket table at hand
+        // (80-float rows keep the 32-atom-tile form: their 2 x 64 x 80 accumulators do not fit two waves per SIMD)
+        if (kg == 8 && !y_or_null && deg_slice_host && (!dx_or_null || f_in == 64) && n_atoms * ld_atoms < (1ll << 30) &&
+            !getenv("JOVA_BWD_OLD") && !getenv("JOVA_BWD_NOPLAN") && !getenv("JOVA_BWD_DB")) {
+            if (num_cu_cached() != hipSuccess) { jova_set_error("graphconv_bwd: cannot query the device"); return JOVA_ERR_HIP; }
+            WavePlan wplan;
+            const int nblk = make_wave_plan(deg_slice_host, n_atoms, 2, g_num_cu, wplan, true);
+            if (nblk < 0) return JOVA_ERR_ARG;
+            if (nblk > 0) {
+#define GC_BWD_WAVE(KG_, DX_, NBR_)                                                                                       \
+    hipLaunchKernelGGL((graphconv_bwd_wave_kernel<KG_, DX_, NBR_>), dim3(nblk), dim3(512), 0, s, (const float*)atoms,        \
+                       (int)n_atoms, (int)ld_atoms, f_in, P, dy, G, gbuf_or_null, dx_or_null, dwp, wplan)
+                if (dx_or_null) GC_BWD_WAVE(8, true, 2);
+                else GC_BWD_WAVE(8, false, 2);
+#undef GC_BWD_WAVE
+                JOVA_CHECK_LAUNCH("graphconv_bwd_wave");
+            }
+            if (dwp) {
+                hipLaunchKernelGGL(graphconv_dw_fold_kernel, dim3(cdiv(21 * 64 * f_in, 256)), dim3(256), 0, s, dwp, G, f_in);
+                JOVA_CHECK_LAUNCH("graphconv_dw_fold");
+            }
+            if (dx_or_null) {
+                JOVA_CHECK_ARG(sym_flag, "graphconv_bwd: sym_flag is null");
+                // many small workgroups (4 waves, `tpw` tiles per wave, one bucket each), descending degree
+                WavePlan dplan;
+                memset(&dplan, 0, sizeof(dplan));
+                long long total_tiles = 0;
+                for (int d = 0; d < NB; ++d) total_tiles += (deg_slice_host[2 * d + 1] + WT - 1) / WT;
+                // one tile per wave up to 2^16 workgroups (measured on the config-4 batch: 42.7 / 46.1 / 59.1 / 84.9 us
+                // with 1 / 2 / 4 / 8 tiles per wave -- the gather latency of a tile is hidden by other waves, not by
+                // the wave's own next tile)
+                const int tpw = (int)std::max<long long>(1, (total_tiles + 4 * 65536 - 1) / (4 * 65536));
+                int blk = 0;
+                for (int k = 0; k < NB; ++k) {
+                    const int d = NB - 1 - k;
+                    dplan.start[d] = (int)deg_slice_host[2 * d];
+                    dplan.size[d] = (int)deg_slice_host[2 * d + 1];
+                    dplan.first[k] = blk;
+                    blk += (int)(((dplan.size[d] + WT - 1) / WT + 4 * tpw - 1) / (4 * tpw));
+                }
+                dplan.first[NB] = blk;
+                if (blk > 0) {
+                    hipLaunchKernelGGL(graphconv_bwd_dx_wave_kernel, dim3(blk), dim3(256), 0, s, dy, (int)n_atoms, P,
+                                       gbuf_or_null, dx_or_null, sym_flag, dplan, tpw);
+                    JOVA_CHECK_LAUNCH("graphconv_bwd_dx_wave");
+                }
+                hipLaunchKernelGGL(graphconv_bwd_dx_scatter_kernel, dim3(2 * g_num_cu), dim3(256), 0, s, (int)n_atoms,
+                                   (const long long*)deg_slice, P, gbuf_or_null, dx_or_null, sym_flag);
+                JOVA_CHECK_LAUNCH("graphconv_bwd_dx_scatter");
+            }
+            return JOVA_OK;
+        }
         const int tiles = cdiv(n_atoms, GT);
         int group = tiles > 2048 ? cdiv(tiles, 2000) : 1;
         if (getenv("JOVA_BWD_GROUP")) group = atoi(getenv("JOVA_BWD_GROUP"));
@@ -2490,9 +3141,6 @@ extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t l
         const bool nodb = getenv("JOVA_BWD_DB") == nullptr;
         const bool db = !y_or_null && !nodb;
         const int nbp = db ? (kg == 8 ? 3 : 2) : 4;
-        // weight rows that are not whole 128-byte lines: accumulate in the aligned scratch image, fold afterwards
-        float* dwp = (dw_scratch_or_null && (f_in & 31) != 0 && !getenv("JOVA_BWD_NO_DWP")) ? dw_scratch_or_null : nullptr;
-        if (dwp) JOVA_CHECK_HIP(hipMemsetAsync(dwp, 0, sizeof(float) * 21 * 64 * DWP_LD, s));
         BwdPlan plan;
         memset(&plan, 0, sizeof(plan));
         if (deg_slice_host && !getenv("JOVA_BWD_NOPLAN")) {

@@ -146,12 +146,13 @@ def test_graphconv_vs_reference_golden(device, tag):
         H.assert_close(x.grad, z[tag + ".gx"], tol=1e-5, what="dx")
 
 
-@pytest.mark.parametrize("mode", ["plan", "noplan", "two_buffers", "generic"])
+@pytest.mark.parametrize("mode", ["plan", "tile32_plan", "noplan", "two_buffers", "generic"])
 @pytest.mark.parametrize("layer_kind", ["l1_relu", "l1_lin", "l2_relu", "l2_lin"])
 def test_graphconv_backward_all_degrees_vs_oracle(device, layer_kind, mode, monkeypatch):
     """Backward of GraphConvLayer on a batch that populates every degree bucket 0..10 (multi-round gathers, short last
-    rounds, partial last tiles) against fp64 autograd of the oracle: the LDS-DMA form with the host work plan, without
-    it, with two LDS buffers, and the generic form.  75 -> 64 from int64 atoms (dW only) and 64 -> 64 (dW + dX), with the
+    rounds, partial last tiles) against fp64 autograd of the oracle: the wave-private form (dZ handed in: the "lin" kinds)
+    / the 32-atom-tile LDS-DMA form with the host work plan, the latter also without it and with two LDS buffers, and the
+    generic form.  75 -> 64 from int64 atoms (dW only) and 64 -> 64 (dW + dX), with the
     ReLU mask applied in the kernel (relu) and without (lin)."""
     from jova_amd import synth
     from jova_amd.nn.layers import GraphConvLayer
@@ -159,7 +160,9 @@ def test_graphconv_backward_all_degrees_vs_oracle(device, layer_kind, mode, monk
     rng = np.random.RandomState(64)
     mols = [synth.make_molecule(rng, int(n), deg_cap=4, hub_frac=0.15) for n in rng.randint(14, 60, size=150)]
     mols.append(synth.make_molecule(rng, 1))             # a degree-0 atom
-    if mode == "noplan":
+    if mode == "tile32_plan":                            # the workgroup-synchronous 32-atom-tile form, also without a mask
+        monkeypatch.setenv("JOVA_BWD_OLD", "1")
+    elif mode == "noplan":
         monkeypatch.setenv("JOVA_BWD_NOPLAN", "1")
         monkeypatch.setenv("JOVA_FWD_NOPLAN", "1")
     elif mode == "two_buffers":

@@ -177,7 +177,7 @@ def test_fit_two_epochs_across_a_scheduler_boundary_vs_oracle(device):
     assert res["epoch"] in (0, 1) and np.isfinite(res["score"]) and len(eval_out) == 2
     # the evaluation score is Jova.evaluate's (nanmean([ci, r2]) - rms) of that epoch's eval-mode outputs
     from oracle import metrics_ref as MR
-    want_scores = [MR.dti_metrics(z["y"][splits[0]], o.numpy(), z["w"][splits[0]])[3] for o in eval_out]
+    want_scores = [MR.dti_metrics(z["y"][splits[0]].astype(np.float32), o.numpy(), z["w"][splits[0]])[3] for o in eval_out]
     assert [abs(h["score"] - wsc) < 1e-9 for h, wsc in zip(hist, want_scores)] == [True, True]
     assert abs(res["score"] - max(want_scores)) < 1e-9 and res["epoch"] == int(np.argmax(want_scores))
     assert not net.training                                        # the loop leaves the model in its last (eval) phase
