@@ -1928,21 +1928,28 @@ graphconv_fwd_wave_kernel(const float* __restrict__ x, int n_atoms, int ldx, int
     for (int d = 0; d < NB; ++d) {
         if (d == deg) { bstart = plan.start[d]; bsize = plan.size[d]; }
     }
-    int chunk = 0;
+    // XCD x (= blockIdx % 8) owns the x-th share of the bucket's tiles (shares in proportion to the XCD's workgroups of
+    // this bucket); inside the share the tiles are dealt round-robin to ALL its waves, so at any moment the XCD's waves
+    // of every bucket work at about the same relative position of their buckets: the rows one bucket streams are the
+    // neighbour rows another gathers, and they meet in that XCD's L2 (a contiguous chunk per workgroup let the buckets
+    // drift apart in time; measured: profiles/r02_pmc_graph.json).
+    int before = 0, mine = 0, rank = 0;
     {
         const int xcd = blockIdx.x & 7, j = (int)blockIdx.x - wg0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int j0 = (k - wg0) & 7;
             const int cnt = j0 < nwg ? (nwg - j0 + 7) >> 3 : 0;
-            chunk += k < xcd ? cnt : 0;
+            before += k < xcd ? cnt : 0;
+            mine = k == xcd ? cnt : mine;
         }
-        chunk += (j - ((xcd - wg0) & 7)) >> 3;
+        rank = (j - ((xcd - wg0) & 7)) >> 3;
     }
     const int tiles = (bsize + WT - 1) / WT;
-    const int per = (tiles + nwg - 1) / nwg;
-    const int t_begin = chunk * per, t_end = min(tiles, t_begin + per);
-    // tiles of this wave: t_begin + wave + 8 n  (claiming them from a per-workgroup counter was measured: the atomic's
+    const int t_begin = (int)((long long)tiles * before / nwg) + rank * 8;
+    const int t_end = (int)((long long)tiles * (before + mine) / nwg);
+    const int tstep = mine * 8;
+    // tiles of this wave: t_begin + wave + tstep n  (claiming them from a per-workgroup counter was measured: the atomic's
     // round trip costs more than the <= 1 tile of imbalance it removes)
     const int t0 = t_begin + wave;
 
@@ -2006,20 +2013,25 @@ graphconv_fwd_wave_kernel(const float* __restrict__ x, int n_atoms, int ldx, int
         }
     };
 
-    // ---- prologue: the first tile's indices are requested first, the bucket's weights (slot 0: W_self, slot 1: W_rel)
-    // go to LDS while they travel, then the first tile's rows are requested: two memory round trips, not five
-    int tc = t0, tn = t0 + 8, tn2 = 0;               // current tile, next (rows in flight), the one after (indices)
-    if (tc < t_end && deg > 0) load_idx(tc, 0);
+    // ---- prologue: the first tile's own rows, its indices and the bucket's weights (slot 0: W_self, slot 1: W_rel) are
+    // requested together, the neighbours' rows as soon as the indices are here, and the weights go to LDS while those
+    // travel: two memory round trips, not five
+    int tc = t0, tn = t0 + tstep, tn2 = 0;               // current tile, next (rows in flight), the one after (indices)
+    if (tc < t_end) {                                    // the first tile's own rows need no indices: they leave first
+#pragma unroll
+        for (int k = 0; k < PPP; ++k) issue_round0_piece(tc, k);
+        if (deg > 0) load_idx(tc, 0);
+    }
 
     const int w_rel = deg > 0 ? 2 * (deg - 1) : 20, w_self = deg == 0 ? 20 : 2 * (deg - 1) + 1;
+    constexpr int NE = (WMAT_F / 4 + 511) / 512;
+    float4 wa[NE], wb[NE];
     {
         // weights straight from the layer's [64][f_in] matrices into fragment order (no separate re-pack launch):
         //   image[mat][fb][m][lane][s] = W[16 fb + (lane & 15)][16 m + 4 (lane >> 4) + s], zero beyond f_in
         const float* W0 = P.w[w_self];
         const float* W1 = P.w[w_rel];
-        constexpr int NE = (WMAT_F / 4 + 511) / 512;
         const bool vec = (f_in & 3) == 0;
-        float4 a[NE], b[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int o = min(tid + 512 * e, WMAT_F / 4 - 1);
@@ -2028,8 +2040,8 @@ graphconv_fwd_wave_kernel(const float* __restrict__ x, int n_atoms, int ldx, int
             if (vec) {
                 const bool ok = k < f_in;
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                a[e] = ok ? *reinterpret_cast<const float4*>(W0 + row * f_in + k) : z;
-                b[e] = ok ? *reinterpret_cast<const float4*>(W1 + row * f_in + k) : z;
+                wa[e] = ok ? *reinterpret_cast<const float4*>(W0 + row * f_in + k) : z;
+                wb[e] = ok ? *reinterpret_cast<const float4*>(W1 + row * f_in + k) : z;
             } else {
                 float va[4], vb[4];
 #pragma unroll
@@ -2042,16 +2054,9 @@ graphconv_fwd_wave_kernel(const float* __restrict__ x, int n_atoms, int ldx, int
                 for (int u = 0; u < 4; ++u) {
                     if (k + u >= f_in) va[u] = vb[u] = 0.f;
                 }
-                a[e] = make_float4(va[0], va[1], va[2], va[3]);
-                b[e] = make_float4(vb[0], vb[1], vb[2], vb[3]);
+                wa[e] = make_float4(va[0], va[1], va[2], va[3]);
+                wb[e] = make_float4(vb[0], vb[1], vb[2], vb[3]);
             }
-        }
-        float4* d0 = reinterpret_cast<float4*>(lds);
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const int o = min(tid + 512 * e, WMAT_F / 4 - 1);        // (the clamped duplicates rewrite the same values)
-            d0[o] = a[e];
-            d0[WMAT_F / 4 + o] = b[e];
         }
     }
     f32x4v bias[4];
@@ -2063,13 +2068,22 @@ graphconv_fwd_wave_kernel(const float* __restrict__ x, int n_atoms, int ldx, int
             bias[fb][r] = P.b[w_self][col] + (deg > 0 ? P.b[w_rel][col] : 0.f);
         }
     }
-    if (tc < t_end) {
+    if (tc < t_end) {                                    // the indices are here: the neighbours' rows
 #pragma unroll
-        for (int k = 0; k < NPL * PPP; ++k) issue_round0_piece(tc, k);
+        for (int k = PPP; k < NPL * PPP; ++k) issue_round0_piece(tc, k);
         if (deg > 0 && tn < t_end) load_idx(tn, 0);
     }
+    {
+        float4* d0 = reinterpret_cast<float4*>(lds);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int o = min(tid + 512 * e, WMAT_F / 4 - 1);        // (the clamped duplicates rewrite the same values)
+            d0[o] = wa[e];
+            d0[WMAT_F / 4 + o] = wb[e];
+        }
+    }
     __syncthreads();                                 // the weights are in LDS: the only barrier in front of the loop
-    tn2 = tn + 8;
+    tn2 = tn + tstep;
     // The two waves of a SIMD (w and w + 4) run the same program; started together they stay in lockstep and meet the
     // matrix pipe, the LDS reads and the stores together.  Half a tile of delay for waves 4..7 puts one wave's
     // read / epilogue phases beside the other's MFMA phase (MI355X_MICROARCH.md, "try a stagger").
@@ -2091,7 +2105,7 @@ graphconv_fwd_wave_kernel(const float* __restrict__ x, int n_atoms, int ldx, int
     const unsigned long long pf_start = __builtin_readcyclecounter();
 #endif
     int n_done = 0;
-    for (; tc < t_end; tc = tn, tn = tn2, tn2 += 8, ++n_done) {
+    for (; tc < t_end; tc = tn, tn = tn2, tn2 += tstep, ++n_done) {
         const int t = tc;
         const int lrow0 = t * WT, rows = min(WT, bsize - lrow0);
         WPROF(p0);
@@ -2281,20 +2295,27 @@ graphconv_bwd_wave_kernel(const float* __restrict__ x, int n_atoms, int ldx, int
     for (int d = 0; d < NB; ++d) {
         if (d == deg) { bstart = plan.start[d]; bsize = plan.size[d]; }
     }
-    int chunk = 0;
+    // XCD x (= blockIdx % 8) owns the x-th share of the bucket's tiles (shares in proportion to the XCD's workgroups of
+    // this bucket); inside the share the tiles are dealt round-robin to ALL its waves, so at any moment the XCD's waves
+    // of every bucket work at about the same relative position of their buckets: the rows one bucket streams are the
+    // neighbour rows another gathers, and they meet in that XCD's L2 (a contiguous chunk per workgroup let the buckets
+    // drift apart in time; measured: profiles/r02_pmc_graph.json).
+    int before = 0, mine = 0, rank = 0;
     {
         const int xcd = blockIdx.x & 7, j = (int)blockIdx.x - wg0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int j0 = (k - wg0) & 7;
             const int cnt = j0 < nwg ? (nwg - j0 + 7) >> 3 : 0;
-            chunk += k < xcd ? cnt : 0;
+            before += k < xcd ? cnt : 0;
+            mine = k == xcd ? cnt : mine;
         }
-        chunk += (j - ((xcd - wg0) & 7)) >> 3;
+        rank = (j - ((xcd - wg0) & 7)) >> 3;
     }
     const int tiles = (bsize + WT - 1) / WT;
-    const int per = (tiles + nwg - 1) / nwg;
-    const int t_begin = chunk * per, t_end = min(tiles, t_begin + per);
+    const int t_begin = (int)((long long)tiles * before / nwg) + rank * 8;
+    const int t_end = (int)((long long)tiles * (before + mine) / nwg);
+    const int tstep = mine * 8;
     const int t0 = t_begin + wave;
 
     float* const pl = lds + WMAT_F + wave * WAVE_F;
@@ -2375,7 +2396,7 @@ graphconv_bwd_wave_kernel(const float* __restrict__ x, int n_atoms, int ldx, int
 
     // ---- prologue: weight loads, the first tile's indices and its index-free pieces (own rows, dZ) leave together; the
     // neighbours' pieces follow as soon as the indices are here (in-order counter: everything but the PPP + 4 pieces)
-    int tc = t0, tn = t0 + 8, tn2 = 0;
+    int tc = t0, tn = t0 + tstep, tn2 = 0;
     const int w_rel = deg > 0 ? 2 * (deg - 1) : 20, w_self = deg == 0 ? 20 : 2 * (deg - 1) + 1;
     float4 wv[2];
     if (DX && deg > 0) {
@@ -2409,7 +2430,7 @@ graphconv_bwd_wave_kernel(const float* __restrict__ x, int n_atoms, int ldx, int
         for (int e = 0; e < 2; ++e) d0[tid + 512 * e] = wv[e];
     }
     __syncthreads();
-    tn2 = tn + 8;
+    tn2 = tn + tstep;
     if (wave >= 4 && JOVA_WAVE_STAGGER > 0) __builtin_amdgcn_s_sleep(JOVA_WAVE_STAGGER);
 
     f32x4v accS[4][NFB], accR[4][NFB];               // dW_self / dW_rel [16 nb + 4 q + r][16 fb + i]
@@ -2428,7 +2449,7 @@ graphconv_bwd_wave_kernel(const float* __restrict__ x, int n_atoms, int ldx, int
     int n_done = 0;
 #endif
 
-    for (; tc < t_end; tc = tn, tn = tn2, tn2 += 8) {
+    for (; tc < t_end; tc = tn, tn = tn2, tn2 += tstep) {
         const int t = tc;
         const int lrow0 = t * WT, rows = min(WT, bsize - lrow0);
         WPROF(p0);
