@@ -42,10 +42,23 @@ WORKLOADS = {
     "metz_psc": ("metz", ["pcnn2d", "psc"], "Metz-shaped DTI joint-view model with the PSC view "
                                             "(ecfp8-gconv__pcnn2d-psc, tuned hparams) fwd+bwd+SGD, B=128 per GPU, "
                                             "synthetic batches resident in HBM"),
+    # proj/dti/train_joint_attn.py:1022-1068 (default_hparams_bopt): B = 256, adamax, three wide head layers
+    "davis_b256_default": ("davis", ["pcnn2d"], "Davis-shaped DTI joint-view model (ecfp8-gconv__pcnn2d, the reference's "
+                                                "DEFAULT hparams: gconv 512, lin_dims 1033/1481/1800, adamax) fwd+bwd+"
+                                                "Adamax, B=256 per GPU, synthetic batches resident in HBM"),
+    # the long-protein stress variant (one protein of 1024 segments in every batch)
+    "long1024": ("long1024", ["pcnn2d"], "long-protein stress variant (P_max = 1024 segments in every batch, tuned Davis "
+                                         "hparams) fwd+bwd+SGD, B=128 per GPU, synthetic batches resident in HBM"),
 }
 
+DEFAULT_HPARAMS_OVERRIDE = {
+    "lin_dims": [1033, 1481, 1800], "dprob": 0.2, "tr_batch_size": 256, "optimizer": "adamax",
+    "optimizer__global__weight_decay": 0.0007, "optimizer__global__lr": 0.0004, "gconv": {"dim": 512},
+    "prot": {"model_types": ["pcnn2d"], "vocab_size": 9048, "window": 11, "pcnn_num_layers": 2, "embedding_dim": 33,
+             "psc_dim": 8421},
+}
 
-EPOCH_PAIRS = {"davis": 25459, "kiba": 118000, "metz": 28245}     # training pairs of one epoch (0.8 of the data set)
+EPOCH_PAIRS = {"davis": 25459, "kiba": 118000, "metz": 28245, "long1024": 25459}     # training pairs of one epoch
 
 
 def build_batches(pool, conv_mols, hp, device, n_batches, prot2vec, shape, world, rank):
@@ -56,6 +69,9 @@ def build_batches(pool, conv_mols, hp, device, n_batches, prot2vec, shape, world
     sampler = ShardSampler(len(mi), world, rank, hp["tr_batch_size"], seed=1)
     out = []
     shard = sampler.indices()
+    if shape == "long1024":                         # every batch holds the 1024-segment protein (pool protein 0)
+        pi = pi.copy()
+        pi[shard[:, 0]] = 0
     for idx in shard[:n_batches]:
         out.append(collate_pairs(pool, conv_mols, mi[idx], pi[idx], y[idx], w[idx], device, prot2vec,
                                  with_psc="psc" in hp["prot"]["model_types"]))
@@ -133,7 +149,17 @@ def cpu_baseline(pool, hp, batch_ids, state_dict, n_steps, threads):
         if step > 0:
             times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    return dict(value=round(hp["tr_batch_size"] / med, 2), unit="pairs/s", cores=threads, kind="port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return dict(value=round(hp["tr_batch_size"] / med, 2), unit="pairs/s", cores=threads, kind="port", cpu=cpu_model,
+                host_cpus=os.cpu_count(),
                 sample="%d timed fwd+bwd+SGD steps (after 1 warm-up) of the fp32 oracle on one Davis-shaped batch of %d "
                        "pairs, median %.2f s/step; oracle collate %.1f ms/batch not included"
                        % (n_steps, hp["tr_batch_size"], med, t_col * 1e3))
@@ -300,7 +326,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph-stress", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="davis",
                     help="davis = BASELINE.json configs[1] (the bench line); kiba / metz_psc = configs[3] / [5] shapes")
     args = ap.parse_args()
@@ -334,6 +360,8 @@ def main():
         pg = torch.distributed.group.WORLD
 
     hp = dict(TUNED_DAVIS_HPARAMS)
+    if args.workload == "davis_b256_default":
+        hp.update(DEFAULT_HPARAMS_OVERRIDE)
     shape, pviews, workload_text = WORKLOADS[args.workload]
     hp["prot"] = dict(hp["prot"], model_types=list(pviews))
     pool = synth.SyntheticPool(shape, seed=1)
@@ -442,7 +470,8 @@ def main():
             line["graph_roofline"] = graph_stress(device)
         if not args.no_cpu_baseline:
             r = np.random.RandomState(1000)
-            threads = min(os.cpu_count() or 1, 16)
+            # the GPU box gives a one-GPU job a 16-CPU share (OMP_NUM_THREADS = 16 there): those are "all host cores"
+            threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
             line["cpu_baseline"] = cpu_baseline(pool, hp, pool.sample_pairs(r, bsz), sd0, args.cpu_steps, threads)
     if rank == 0:
         print(json.dumps(line), flush=True)
