@@ -333,9 +333,12 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if os.environ.get("JOVA_BENCH_WATCHDOG"):              # a stuck run dumps every thread's stack and exits
+    # a stuck run dumps every thread's stack and exits instead of hanging: always on for a multi-rank run (a rank that
+    # never reaches a collective would otherwise hold the others forever), on request for one rank
+    watchdog = os.environ.get("JOVA_BENCH_WATCHDOG") or ("900" if world > 1 else "")
+    if watchdog and float(watchdog) > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ["JOVA_BENCH_WATCHDOG"]), exit=True)
+        faulthandler.dump_traceback_later(float(watchdog), exit=True)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))

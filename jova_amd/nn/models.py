@@ -87,7 +87,7 @@ class NwayForward(nn.Module):
 class ProteinTable(object):
     """All protein profiles of a ``protein_profile`` dict resident in HBM as one int32 table [rows, window]."""
 
-    def __init__(self, protein_profile, device):
+    def __init__(self, protein_profile, device, vocab_size=None):
         self.names = list(protein_profile.keys())
         self.row_of = {}
         rows, off = [], 0
@@ -101,6 +101,11 @@ class ProteinTable(object):
             rows.append(prof.astype(np.int32))
             off += prof.shape[0]
         table = np.concatenate(rows, axis=0) if rows else np.zeros((0, 1), np.int32)
+        if vocab_size is not None and table.size and (table.min() < 0 or table.max() > vocab_size):
+            # nn.Embedding raises on such an index at lookup time (models.py:704-715); the kernels index the table
+            # without a test per element, so the table is checked once, here
+            raise IndexError("protein profile holds word ids outside [0, %d] (min %d, max %d): index out of range"
+                             % (vocab_size, int(table.min()), int(table.max())))
         self.table = torch.from_numpy(np.ascontiguousarray(table)).to(device)
 
     def batch_meta(self, prot_x):
@@ -138,7 +143,7 @@ class Prot2Vec(nn.Module):
 
     def _resident_table(self, device):
         if self._table is None or self._table.table.device != device:
-            self._table = ProteinTable(self.protein_profile, device)
+            self._table = ProteinTable(self.protein_profile, device, vocab_size=self.embedding.num_embeddings - 1)
         return self._table
 
     def forward(self, input):

@@ -257,3 +257,16 @@ def test_native_collate_rejects_bad_molecules():
         gconv_input_list([m], torch.device("cpu"))
     empty = gconv_input_list([], torch.device("cpu"))   # an empty batch is legal
     assert empty[0].shape[0] == 0 and empty[3] == []
+
+
+def test_protein_table_rejects_word_ids_outside_the_vocabulary():
+    """nn.Embedding raises IndexError on an id > num_embeddings - 1 (models.py:704-715); the resident table is checked
+    once when it is built (construction fails before any device work)."""
+    from jova_amd.nn.models import ProteinTable
+    prof = {"P0": np.array([[0, 5, 60]] * 2, dtype=np.int64), "P1": np.array([[3, 61, 2]], dtype=np.int64)}
+    with pytest.raises(IndexError):
+        ProteinTable(prof, torch.device("cpu"), vocab_size=60)
+    with pytest.raises(IndexError):
+        ProteinTable({"P0": np.array([[-1, 2, 3]])}, torch.device("cpu"), vocab_size=60)
+    t = ProteinTable({"P0": prof["P0"]}, torch.device("cpu"), vocab_size=60)      # the padding id (= vocab) is legal
+    assert t.table.shape == (2, 3) and t.row_of["P0"] == (0, 2)
