@@ -2668,6 +2668,372 @@ graphconv_bwd_wave_kernel(const float* __restrict__ x, int n_atoms, int ldx, int
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ backward, dW only, waves by matrix
+// 80-float rows (75 -> 64): the 2 x 64 x 80 weight-gradient accumulators are 160 registers per lane, which with the
+// fragments does not fit the 256 a wave may hold when two share a SIMD.  Here the two waves of a SIMD (w and w + 4)
+// work on the SAME tiles and each carries ONE matrix: waves 0..3 dW_self += dZ^T X (planes: own rows, dZ), waves 4..7
+// dW_rel += dZ^T S (planes: four neighbours, dZ) -- 80 accumulator registers each, the same 2 x 16 x 5 MFMAs per tile and
+// SIMD, no workgroup barrier before the final reduction, and with four neighbour planes only atoms of degree > 4 need
+// a second gather round.  A tile's neighbour indices are ONE load of its contiguous adjacency block (16 x degree ints,
+// up to three registers) and cross-lane reads, instead of one load per (plane, row group).
+template <int KG>
+__global__ void __launch_bounds__(512, 1)
+graphconv_bwd_split_kernel(const float* __restrict__ x, int n_atoms, int ldx, int f_in, GcParams P,
+                           const float* __restrict__ dz, GcGrads Gd, float* __restrict__ dwp, WavePlan plan) {
+    constexpr int NFB = KG / 2;
+    constexpr int NBR = 4;
+    constexpr int PPP = KG > 8 ? 5 : 4;
+    constexpr int TAIL_F = KG > 8 ? WT * 16 : 0;
+    constexpr int PLANE_F = WT * 64 + TAIL_F;
+    constexpr int SELF_F = PLANE_F + WT * 64;            // own rows, dZ
+    constexpr int REL_F = NBR * PLANE_F + WT * 64;       // neighbour planes, dZ
+    constexpr int ACC_F = 16 * NFB * 64;
+    static_assert(4 * ACC_F + 4 * 64 <= 4 * (SELF_F + REL_F), "the reduction image must fit in the planes");
+    __shared__ __attribute__((aligned(16))) float lds[4 * (SELF_F + REL_F)];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 15, q = lane >> 4;
+    const bool rel = wave >= 4;
+    const int pair = wave & 3;
+
+    int kb = 0;
+#pragma unroll
+    for (int k = 1; k < NB; ++k) kb += ((int)blockIdx.x >= plan.first[k]) ? 1 : 0;
+    const int deg = NB - 1 - kb;
+    const int wg0 = plan.first[kb], nwg = plan.first[kb + 1] - wg0;
+    int bstart = 0, bsize = 0;
+#pragma unroll
+    for (int d = 0; d < NB; ++d) {
+        if (d == deg) { bstart = plan.start[d]; bsize = plan.size[d]; }
+    }
+    int before = 0, mine = 0, rank = 0;
+    {
+        const int xcd = blockIdx.x & 7, j = (int)blockIdx.x - wg0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j0 = (k - wg0) & 7;
+            const int cnt = j0 < nwg ? (nwg - j0 + 7) >> 3 : 0;
+            before += k < xcd ? cnt : 0;
+            mine = k == xcd ? cnt : mine;
+        }
+        rank = (j - ((xcd - wg0) & 7)) >> 3;
+    }
+    const int tiles = (bsize + WT - 1) / WT;
+    const int t_begin = (int)((long long)tiles * before / nwg) + rank * 4;
+    const int t_end = (rel && deg == 0) ? 0 : (int)((long long)tiles * (before + mine) / nwg);
+    const int tstep = mine * 4;
+
+    float* const pl = lds + (rel ? 4 * SELF_F + pair * REL_F : pair * SELF_F);
+    float* const zpl = pl + (rel ? NBR * PLANE_F : PLANE_F);
+    const unsigned pl_addr = lds_byte_addr(pl);
+    const unsigned z_addr = lds_byte_addr(zpl);
+    const int* adj_d = deg > 0 ? P.adj[deg - 1] : nullptr;
+    const unsigned nmax = (unsigned)(n_atoms - 1);
+    const int cnt0 = min(deg, NBR);
+    const int nraw = (16 * deg + 63) >> 6;               // registers of a tile's adjacency block (<= 3)
+    const unsigned ldx4 = (unsigned)ldx * 4u;
+    const unsigned ch16 = (unsigned)(((lane & 15) ^ q) << 4);
+    const unsigned cht = 256u + (unsigned)((((lane & 3) ^ ((4 - (lane >> 4)) & 3))) << 4);
+
+    auto issue_x_piece = [&](int pp, int j, unsigned row) {
+        if (j < 4) dma16_m0_s(x, min(row, nmax) * ldx4 + (ch16 ^ (unsigned)(j << 6)), pl_addr + (pp * PLANE_F + j * 256) * 4);
+        else dma16_m0_s(x, min(row, nmax) * ldx4 + cht, pl_addr + (pp * PLANE_F + WT * 64) * 4);
+    };
+    auto issue_z_piece = [&](int t, int j) {
+        const int lrow0 = t * WT, rows = min(WT, bsize - lrow0);
+        const unsigned row = (unsigned)(bstart + lrow0 + min(4 * j + q, rows - 1));
+        dma16_m0_s(dz, min(row, nmax) * 256u + (ch16 ^ (unsigned)(j << 6)), z_addr + j * 1024);
+    };
+    auto issue_own_piece = [&](int t, int j) {
+        const int lrow0 = t * WT, rows = min(WT, bsize - lrow0);
+        issue_x_piece(0, j, (unsigned)(bstart + lrow0 + min(j < 4 ? 4 * j + q : lane >> 2, rows - 1)));
+    };
+    // the tile's adjacency block: element e = (local row) * deg + p, register e >> 6, lane e & 63
+    auto load_raw = [&](int t, int (&raw)[3]) {
+        const int lrow0 = t * WT, rows = min(WT, bsize - lrow0);
+        const unsigned last = (unsigned)(rows * deg - 1);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            if (u < nraw) raw[u] = adj_d[(unsigned)(lrow0 * deg) + min((unsigned)(64 * u + lane), last)];
+        }
+    };
+    auto pick = [&](const int (&raw)[3], int t, int r, int p) -> unsigned {        // neighbour p of local row r
+        const int rows = min(WT, bsize - t * WT);
+        const int e = min(r, rows - 1) * deg + p;
+        int v = __shfl(raw[0], e & 63, 64);
+        if (nraw > 1) { const int v1 = __shfl(raw[1], e & 63, 64); v = (e >> 6) == 1 ? v1 : v; }
+        if (nraw > 2) { const int v2 = __shfl(raw[2], e & 63, 64); v = (e >> 6) == 2 ? v2 : v; }
+        return (unsigned)v;
+    };
+    const int tsw = (i >> 2);
+    const int lane_t = q * 64 + ((tsw ^ q) << 2) + (i & 3);
+    const int lane_tt = q * 16 + (i & 3);
+    auto read_plane_t = [&](const float* b, float (&f)[NFB][4], bool add) {
+        const float* bl = b + lane_t;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) {
+                float v;
+                if (fb < 4) v = bl[ks * 256 + ((fb ^ ks) << 4)];
+                else v = b[WT * 64 + ks * 64 + lane_tt + ((tsw ^ ((4 - ks) & 3)) << 2)];
+                f[fb][ks] = add ? f[fb][ks] + v : v;
+            }
+        }
+    };
+
+    f32x4v acc[4][NFB];
+    float dbacc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        dbacc[nb] = 0.f;
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) acc[nb][fb] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    }
+    int tc = t_begin + pair, tn = tc + tstep;
+#ifdef JOVA_WAVE_PROFILE
+    unsigned long long pf[3] = {0, 0, 0}, pf_mid = 0;
+    int n_done = 0;
+    const unsigned long long pw_entry = wall_clock64();
+#endif
+    if (!rel) {
+        // ================================================================ waves 0..3: dW_self (and db)
+        if (tc < t_end) {
+#pragma unroll
+            for (int j = 0; j < PPP; ++j) issue_own_piece(tc, j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) issue_z_piece(tc, j);
+        }
+        for (; tc < t_end; tc = tn, tn += tstep) {
+            const int rows = min(WT, bsize - tc * WT);
+            WPROF(p0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            asm volatile("" ::: "memory");
+            WPROF(p1);
+            float zt[4][4], xs[NFB][4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bool live = 4 * ks + q < rows;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const float v = zpl[lane_t + ks * 256 + ((nb ^ ks) << 4)];
+                    zt[nb][ks] = live ? v : 0.f;
+                }
+            }
+            read_plane_t(pl, xs, false);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) dbacc[nb] += (zt[nb][0] + zt[nb][1]) + (zt[nb][2] + zt[nb][3]);
+            WPROF(p2);
+            const bool nxt = tn < t_end;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const int k = 4 * ks + nb;
+                    if (nxt && k < PPP) issue_own_piece(tn, k);
+                    else if (nxt && k < PPP + 4) issue_z_piece(tn, k - PPP);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int fb = 0; fb < NFB; ++fb)
+                        acc[nb][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[nb][ks], xs[fb][ks], acc[nb][fb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#ifdef JOVA_WAVE_PROFILE
+            asm volatile("s_nop 0" ::"v"(acc[3][NFB - 1]));
+            const unsigned long long p3 = __builtin_readcyclecounter();
+            pf[0] += p1 - p0; pf[1] += p2 - p1; pf[2] += p3 - p2; ++n_done;
+#endif
+        }
+    } else {
+        // ================================================================ waves 4..7: dW_rel
+        int raw_c[3] = {0, 0, 0}, raw_n[3] = {0, 0, 0};
+        unsigned ixn[NBR][4], ixtn[NBR];
+        // rows (in the DMA's lane -> row map) of gather round nb0 of tile t, from its adjacency block
+        const int eb[4] = {q * deg, (4 + q) * deg, (8 + q) * deg, (12 + q) * deg};
+        const int ebt = (lane >> 2) * deg;
+        auto rows_of = [&](const int (&raw)[3], int t, int nb0) {
+            if (nraw == 1) {
+                // degree <= 4 (the block is one register): all cross-lane reads are issued back to back, no select, no
+                // wait in between (planes beyond the degree read a clamped element and are never issued)
+                // (element numbers from per-lane constants: a 32-bit multiply is a quarter-rate instruction; rows past a
+                // partial tile's end read its last element, they only need a valid row: their dZ is zeroed)
+                const int last = min(WT, bsize - t * WT) * deg - 1;
+#pragma unroll
+                for (int p = 0; p < NBR; ++p) {
+                    if (p < deg) {                      // (wave-uniform: a cross-lane read costs ~70 cycles here)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ixn[p][j] = (unsigned)__shfl(raw[0], min(eb[j] + p, last), 64);
+                        if (KG > 8) ixtn[p] = (unsigned)__shfl(raw[0], min(ebt + p, last), 64);
+                    }
+                }
+                return;
+            }
+#pragma unroll
+            for (int p = 0; p < NBR; ++p) {
+                if (nb0 + p < deg) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ixn[p][j] = pick(raw, t, 4 * j + q, nb0 + p);
+                    if (KG > 8) ixtn[p] = pick(raw, t, lane >> 2, nb0 + p);
+                }
+            }
+        };
+        if (tc < t_end) {
+            load_raw(tc, raw_c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) issue_z_piece(tc, j);
+            rows_of(raw_c, tc, 0);
+#pragma unroll
+            for (int p = 0; p < NBR; ++p) {
+                if (p < cnt0) {
+#pragma unroll
+                    for (int j = 0; j < PPP; ++j) issue_x_piece(p, j, j < 4 ? ixn[p][j < 4 ? j : 0] : ixtn[p]);
+                }
+            }
+            if (tn < t_end) load_raw(tn, raw_n);
+        }
+        for (; tc < t_end; tc = tn, tn += tstep) {
+            const int rows = min(WT, bsize - tc * WT);
+            WPROF(p0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            asm volatile("" ::: "memory");
+            WPROF(p1);
+            float zt[4][4], xn[NFB][4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bool live = 4 * ks + q < rows;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const float v = zpl[lane_t + ks * 256 + ((nb ^ ks) << 4)];
+                    zt[nb][ks] = live ? v : 0.f;
+                }
+            }
+            read_plane_t(pl, xn, false);
+            // (this wave has registers to spare: the planes are read together, one LDS round trip for all of them)
+#pragma unroll
+            for (int p = 1; p < NBR; ++p) {
+                if (p < deg) read_plane_t(pl + p * PLANE_F, xn, true);
+            }
+            for (int nb0 = NBR; nb0 < deg; nb0 += NBR) {            // degree > 4: further gather rounds
+                rows_of(raw_c, tc, nb0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the planes' previous contents have been read
+#pragma unroll
+                for (int p = 0; p < NBR; ++p) {
+                    if (nb0 + p < deg) {
+#pragma unroll
+                        for (int j = 0; j < PPP; ++j) issue_x_piece(p, j, j < 4 ? ixn[p][j < 4 ? j : 0] : ixtn[p]);
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int p = 0; p < NBR; ++p) {
+                    if (nb0 + p < deg) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        read_plane_t(pl + p * PLANE_F, xn, true);
+                    }
+                }
+            }
+            const bool nxt = tn < t_end;
+#ifdef JOVA_WAVE_PROFILE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long p15 = __builtin_readcyclecounter();
+            pf_mid += p15 - p1;
+#endif
+            if (nxt) rows_of(raw_n, tn, 0);                          // (the block of tile tn arrived a tile ago)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            WPROF(p2);
+            // 16 MFMA groups; in front of group k: piece k and piece k + 16 of the next tile (4 of dZ, then 5 per plane)
+            auto side = [&](int k) {
+                if (!nxt) return;
+                if (k < 4) { issue_z_piece(tn, k); return; }
+                const int pp = (k - 4) / PPP, j = (k - 4) % PPP;
+                if (pp < cnt0) issue_x_piece(pp, j, j < 4 ? ixn[pp < NBR ? pp : 0][j < 4 ? j : 0] : ixtn[pp < NBR ? pp : 0]);
+            };
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const int k = 4 * ks + nb;
+                    side(k);
+                    if (k + 16 < 4 + NBR * PPP) side(k + 16);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int fb = 0; fb < NFB; ++fb)
+                        acc[nb][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[nb][ks], xn[fb][ks], acc[nb][fb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#ifdef JOVA_WAVE_PROFILE
+            asm volatile("s_nop 0" ::"v"(acc[3][NFB - 1]));
+            const unsigned long long p3 = __builtin_readcyclecounter();
+            pf[0] += p1 - p0; pf[1] += p2 - p1; pf[2] += p3 - p2; ++n_done;
+#endif
+#pragma unroll
+            for (int u = 0; u < 3; ++u) raw_c[u] = raw_n[u];
+            if (tn + tstep < t_end) load_raw(tn + tstep, raw_n);
+        }
+    }
+
+#ifdef JOVA_WAVE_PROFILE
+    const unsigned long long pw_end = wall_clock64();
+    if (lane == 0 && blockIdx.x < 256) {
+        unsigned long long* o = g_wave_prof + (blockIdx.x * 8 + wave) * 8;
+        o[0] = pf[0]; o[1] = pf[1]; o[2] = rel; o[3] = pf[2]; o[4] = pw_end - pw_entry; o[5] = pf_mid; o[6] = n_done; o[7] = deg;
+    }
+#endif
+    // ---- reduction over the four waves of each matrix (through the planes), one atomic per element and workgroup
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const int w_rel = deg > 0 ? 2 * (deg - 1) : 20, w_self = deg == 0 ? 20 : 2 * (deg - 1) + 1;
+    float* const red = lds;                               // [4 waves][ACC_F], then [4 waves][64] column sums of dZ
+    float* const dbred = red + 4 * ACC_F;
+    const int ldw = dwp ? DWP_LD : f_in;
+#pragma unroll
+    for (int mat = 0; mat < 2; ++mat) {
+        if (mat == 1 && deg == 0) break;                  // (workgroup-uniform)
+        __syncthreads();
+        if (rel == (mat == 1)) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb)
+                    *reinterpret_cast<f32x4v*>(red + pair * ACC_F + ((nb * NFB + fb) * 64 + lane) * 4) = acc[nb][fb];
+            if (mat == 0) {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    float s = dbacc[nb];
+                    s += __shfl_xor(s, 16, 64);
+                    s += __shfl_xor(s, 32, 64);
+                    if (q == 0) dbred[pair * 64 + 16 * nb + i] = s;
+                }
+            }
+        }
+        __syncthreads();
+        float* const dst = dwp ? dwp + (long long)(mat == 0 ? w_self : w_rel) * 64 * DWP_LD : Gd.dw[mat == 0 ? w_self : w_rel];
+        for (int e = tid; e < ACC_F / 4; e += 512) {
+            const float4 a = *reinterpret_cast<const float4*>(red + 4 * e);
+            const float4 b = *reinterpret_cast<const float4*>(red + ACC_F + 4 * e);
+            const float4 c = *reinterpret_cast<const float4*>(red + 2 * ACC_F + 4 * e);
+            const float4 d = *reinterpret_cast<const float4*>(red + 3 * ACC_F + 4 * e);
+            const int ln = e & 63, bf = e >> 6;
+            const int o = 16 * (bf / NFB) + 4 * (ln >> 4), k = 16 * (bf % NFB) + (ln & 15);
+            if (k < f_in) {
+                atomicAdd(&dst[(o + 0) * ldw + k], (a.x + b.x) + (c.x + d.x));
+                atomicAdd(&dst[(o + 1) * ldw + k], (a.y + b.y) + (c.y + d.y));
+                atomicAdd(&dst[(o + 2) * ldw + k], (a.z + b.z) + (c.z + d.z));
+                atomicAdd(&dst[(o + 3) * ldw + k], (a.w + b.w) + (c.w + d.w));
+            }
+        }
+        if (mat == 0 && tid < 64) {
+            const float s = (dbred[tid] + dbred[64 + tid]) + (dbred[128 + tid] + dbred[192 + tid]);
+            atomicAdd(&Gd.db[w_self][tid], s);
+            if (deg > 0) atomicAdd(&Gd.db[w_rel][tid], s);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ dx of the wave-private backward
 // dx[a] = dZ[a] W_self[deg(a)]  +  sum over a's neighbours n of G[n]      (G = dZ W_rel from graphconv_bwd_wave_kernel)
 // Memory-bound (reads dZ and the gathered G rows, writes dx), so the 64 MFMAs per 16-atom tile of the own share ride
@@ -2924,7 +3290,10 @@ static int make_wave_plan(const int64_t* dsh, int64_t n_atoms, int nbr, int num_
         static const double rel2[NB] = {0.6, 1.0, 1.08, 1.35, 1.45, 1.70, 1.80, 2.05, 2.15, 2.40, 2.50};
         // backward (two neighbour planes, G + dW phases; tools/prof_wave_bwd.py)
         static const double relb[NB] = {0.45, 1.0, 1.08, 1.39, 1.47, 1.71, 1.77, 1.99, 2.06, 2.30, 2.36};
-        cost[d] = (double)((sz + WT - 1) / WT) * (bwd ? relb[d] : nbr >= 3 ? rel3[d] : rel2[d]);
+        // backward with waves by matrix (four neighbour planes: a second gather round only beyond degree 4)
+        // (measured per tile of the dW_rel waves, which bound it: tools/prof_split_bwd.py)
+        static const double rels[NB] = {0.65, 1.0, 1.12, 1.21, 1.24, 1.80, 2.07, 2.27, 2.48, 3.03, 3.27};
+        cost[d] = (double)((sz + WT - 1) / WT) * (bwd ? (nbr >= 4 ? rels[d] : relb[d]) : nbr >= 3 ? rel3[d] : rel2[d]);
         total += cost[d];
     }
     if (total <= 0.0) return 0;
@@ -3101,7 +3470,24 @@ extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t l
         float* dwp = (dw_scratch_or_null && (f_in & 31) != 0 && !getenv("JOVA_BWD_NO_DWP")) ? dw_scratch_or_null : nullptr;
         if (dwp) JOVA_CHECK_HIP(hipMemsetAsync(dwp, 0, sizeof(float) * 21 * 64 * DWP_LD, s));
         // wave-private form (see graphconv_bwd_wave_kernel): dZ handed in, host copy of the bucket table at hand
-        // (80-float rows keep the 32-atom-tile form: their 2 x 64 x 80 accumulators do not fit two waves per SIMD)
+        // 80-float rows, dW only: waves specialised by matrix (graphconv_bwd_split_kernel)
+        if (kg == 10 && !dx_or_null && !y_or_null && deg_slice_host && n_atoms * ld_atoms < (1ll << 30) &&
+            !getenv("JOVA_BWD_OLD") && !getenv("JOVA_BWD_NOPLAN") && !getenv("JOVA_BWD_DB")) {
+            if (num_cu_cached() != hipSuccess) { jova_set_error("graphconv_bwd: cannot query the device"); return JOVA_ERR_HIP; }
+            WavePlan wplan;
+            const int nblk = make_wave_plan(deg_slice_host, n_atoms, 4, g_num_cu, wplan, true);
+            if (nblk < 0) return JOVA_ERR_ARG;
+            if (nblk > 0) {
+                hipLaunchKernelGGL((graphconv_bwd_split_kernel<10>), dim3(nblk), dim3(512), 0, s, (const float*)atoms,
+                                   (int)n_atoms, (int)ld_atoms, f_in, P, dy, G, dwp, wplan);
+                JOVA_CHECK_LAUNCH("graphconv_bwd_split");
+            }
+            if (dwp) {
+                hipLaunchKernelGGL(graphconv_dw_fold_kernel, dim3(cdiv(21 * 64 * f_in, 256)), dim3(256), 0, s, dwp, G, f_in);
+                JOVA_CHECK_LAUNCH("graphconv_dw_fold");
+            }
+            return JOVA_OK;
+        }
         if (kg == 8 && !y_or_null && deg_slice_host && (!dx_or_null || f_in == 64) && n_atoms * ld_atoms < (1ll << 30) &&
             !getenv("JOVA_BWD_OLD") && !getenv("JOVA_BWD_NOPLAN") && !getenv("JOVA_BWD_DB")) {
             if (num_cu_cached() != hipSuccess) { jova_set_error("graphconv_bwd: cannot query the device"); return JOVA_ERR_HIP; }
