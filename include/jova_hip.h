@@ -221,6 +221,18 @@ int jova_optim_step(int kind, float* params, const float* grads, float* state1, 
  * device->host read per batch */
 int jova_nonfinite_flag(const float* x, int64_t n, int* flag, void* stream);
 
+/* ---- GraphNeuralNet / GraphNeuralNet2D (jova/nn/models.py:352-418), section 8(f3) ----------------------------- */
+/* nn.Embedding of the fingerprint ids: out[r][:] = weight[idx[r]][:]; an id outside [0, vocab) (nn.Embedding raises) sets
+ * *bad_flag |= 1 and writes NaN.  Backward: dweight[idx[r]][:] += dout[r][:] (float atomics). */
+int jova_embedding_fwd(const float* weight, const int64_t* idx, int64_t n, int d, int64_t vocab, float* out,
+                       int* bad_flag, void* stream);
+int jova_embedding_bwd(const float* dout, const int64_t* idx, int64_t n, int d, int64_t vocab, float* dweight,
+                       void* stream);
+/* update_fingerprints (models.py:364-372) after the matmul: out = x + y / (m[row] - 1) ("mean"), out = x + y (m NULL,
+ * "sum"); x NULL = the scaled y alone (backward). */
+int jova_rowscale_add(const float* x_or_null, const float* y, const float* m_or_null, int64_t rows, int cols, float* out,
+                      void* stream);
+
 /* ---- evaluation metrics ---------------------------------------------------------------------------------------- */
 /* The metrics Jova.evaluate takes per evaluation batch (proj/dti/train_joint_attn.py:335-343 through
  * jova/metrics/all_metrics.py:80-104 and jova/metrics/cindex_measure.py:15-38, whose pair count is

@@ -393,6 +393,74 @@ extern "C" int jova_axpy(const float* x, float a, int64_t n, float* y, void* str
     return JOVA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ GraphNeuralNet pieces
+// nn.Embedding forward / backward (jova/nn/models.py:362, :376: the fingerprint embedding of GraphNeuralNet) and the
+// residual update x + (A hs) / (M - 1) of update_fingerprints (:364-372); 16 lanes per row, float4 when d % 4 == 0
+__global__ void embedding_fwd_kernel(const float* __restrict__ w, const long long* __restrict__ idx, long long n, int d,
+                                     long long vocab, float* __restrict__ out, int* __restrict__ bad) {
+    const long long total = n * d;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / d;
+        const int c = (int)(e - r * d);
+        const long long k = idx[r];
+        if (k < 0 || k >= vocab) {               // nn.Embedding raises: flag it (read by the caller off the hot loop), emit NaN
+            if (c == 0) atomicOr(bad, 1);
+            out[e] = __int_as_float(0x7fc00000);
+        } else {
+            out[e] = w[k * d + c];
+        }
+    }
+}
+__global__ void embedding_bwd_kernel(const float* __restrict__ dout, const long long* __restrict__ idx, long long n, int d,
+                                     long long vocab, float* __restrict__ dw) {
+    const long long total = n * d;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / d;
+        const int c = (int)(e - r * d);
+        const long long k = idx[r];
+        if (k >= 0 && k < vocab) atomicAdd(&dw[k * d + c], dout[e]);
+    }
+}
+// out = x (or 0) + y * s[row],  s[row] = 1 / (m[row] - 1) when m is given, else 1
+__global__ void rowscale_add_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ m,
+                                    long long rows, int cols, float* __restrict__ out) {
+    const long long total = rows * cols;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / cols;
+        float v = y[e];
+        if (m) v = v / (m[r] - 1.f);
+        out[e] = x ? x[e] + v : v;
+    }
+}
+
+extern "C" int jova_embedding_fwd(const float* weight, const int64_t* idx, int64_t n, int d, int64_t vocab, float* out,
+                                  int* bad_flag, void* stream) {
+    JOVA_CHECK_ARG(n >= 0 && d >= 1 && vocab >= 1 && bad_flag && (n == 0 || (weight && idx && out)), "embedding_fwd: bad argument");
+    if (n == 0) return JOVA_OK;
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(ew_blocks(n * d)), dim3(256), 0, (hipStream_t)stream, weight,
+                       (const long long*)idx, (long long)n, d, (long long)vocab, out, bad_flag);
+    JOVA_CHECK_LAUNCH("embedding_fwd");
+    return JOVA_OK;
+}
+extern "C" int jova_embedding_bwd(const float* dout, const int64_t* idx, int64_t n, int d, int64_t vocab, float* dweight,
+                                  void* stream) {
+    JOVA_CHECK_ARG(n >= 0 && d >= 1 && vocab >= 1 && (n == 0 || (dout && idx && dweight)), "embedding_bwd: bad argument");
+    if (n == 0) return JOVA_OK;
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(ew_blocks(n * d)), dim3(256), 0, (hipStream_t)stream, dout,
+                       (const long long*)idx, (long long)n, d, (long long)vocab, dweight);
+    JOVA_CHECK_LAUNCH("embedding_bwd");
+    return JOVA_OK;
+}
+extern "C" int jova_rowscale_add(const float* x_or_null, const float* y, const float* m_or_null, int64_t rows, int cols,
+                                 float* out, void* stream) {
+    JOVA_CHECK_ARG(rows >= 0 && cols >= 1 && (rows == 0 || (y && out)), "rowscale_add: bad argument");
+    if (rows == 0) return JOVA_OK;
+    hipLaunchKernelGGL(rowscale_add_kernel, dim3(ew_blocks(rows * cols)), dim3(256), 0, (hipStream_t)stream, x_or_null, y,
+                       m_or_null, (long long)rows, cols, out);
+    JOVA_CHECK_LAUNCH("rowscale_add");
+    return JOVA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ error channel
 #include <stdarg.h>
 static thread_local char g_err[512] = "";

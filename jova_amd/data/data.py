@@ -85,17 +85,46 @@ def process_gconv_view_data(X, prot_desc_dict, idx, cuda_prot):
     return mol_data, prots_tensor, prot_names, x_data
 
 
+def process_gnn_view_data(X, prot_desc_dict, idx, cuda_prot):
+    """data.py:309-335 -> (mol_data, prots_tensor, prot_names, x_data) with
+    mol_data = (fingerprints int64 [N], block-diagonal adjacency float [N, N], M float [N, 1], axis = atoms per molecule).
+    The block-diagonal matrix, M and the ids are laid out in ONE pinned buffer and go up in one copy (the reference
+    uploads every molecule's fingerprint tensor by itself and builds the block matrix with torch ops)."""
+    x_data = X[:, 0, idx]
+    mols = [pair[0] for pair in x_data]
+    axis = [len(m.fingerprints) for m in mols]
+    n = int(sum(axis))
+    dev = _device()
+    pin = dev.type == "cuda"
+    buf = torch.empty(n * n + n + 2 * n, dtype=torch.float32, pin_memory=pin)     # A | M | ids (int64 = 2 floats each)
+    a = buf[:n * n].view(n, n).numpy()
+    a[:] = 0.0
+    mv = buf[n * n:n * n + n].numpy()
+    ids = buf[n * n + n:].view(torch.int64).numpy()
+    o = 0
+    for m, k in zip(mols, axis):
+        a[o:o + k, o:o + k] = np.asarray(m.adjacency, dtype=np.float32)
+        mv[o:o + k] = k
+        ids[o:o + k] = np.asarray(m.fingerprints, dtype=np.int64)
+        o += k
+    d = buf.to(dev, non_blocking=True)
+    mol_data = (d[n * n + n:].view(torch.int64), d[:n * n].view(n, n), d[n * n:n * n + n].view(n, 1), axis)
+    prots_tensor, prot_names = _protein_tensor(x_data, prot_desc_dict, cuda_prot)
+    return mol_data, prots_tensor, prot_names, x_data
+
+
 def batch_collator(batch, prot_desc_dict, spec, cuda_prot=True):
     """data.py:166-187 -> (batch_size, {view: ((view data ...), y [B] object array, w [B] object array)}).
     ``spec``: a dict {view name: active?} (iteration order = view index in the batch) or a single view name.
-    Views of the hot path: ecfp4 / ecfp8 / gconv; weave and gnn are other model families."""
+    Views: ecfp4 / ecfp8 / gconv (the hot path) and gnn (section 8 f3); weave is not built."""
     batch = _as_batch_array(batch)
-    funcs = {"ecfp4": process_ecfp_view_data, "ecfp8": process_ecfp_view_data, "gconv": process_gconv_view_data}
+    funcs = {"ecfp4": process_ecfp_view_data, "ecfp8": process_ecfp_view_data, "gconv": process_gconv_view_data,
+             "gnn": process_gnn_view_data}
     active_views = [k for k in spec if spec[k]] if isinstance(spec, dict) else [spec]
     data = {}
     for i, v_name in enumerate(active_views):
         if v_name not in funcs:
-            raise NotImplementedError("view %r is outside the hot path (SURVEY.md section 8); have %s"
+            raise NotImplementedError("view %r is not built (SURVEY.md section 8); have %s"
                                       % (v_name, sorted(funcs)))
         data[v_name] = (funcs[v_name](batch, prot_desc_dict, i, cuda_prot), batch[:, 1, i], batch[:, 2, i])
     return len(batch), data

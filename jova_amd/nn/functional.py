@@ -699,6 +699,71 @@ class JointAttentionFunction(torch.autograd.Function):
         return (None, None, None, None, None, None) + tuple(grads_in) + tuple(sink.returns)
 
 
+class EmbeddingFunction(torch.autograd.Function):
+    """nn.Embedding lookup of int64 ids (GraphNeuralNet.embed_fingerprint, jova/nn/models.py:362, :376)."""
+    bad_flag = None          # device int: an id outside [0, vocab) was seen (nn.Embedding raises there); see raise_if_bad
+
+    @staticmethod
+    def forward(ctx, weight, idx):
+        _lib.require_gpu(weight, idx)
+        idx = idx.reshape(-1).to(torch.int64).contiguous()
+        n, d = idx.numel(), weight.shape[1]
+        if EmbeddingFunction.bad_flag is None or EmbeddingFunction.bad_flag.device != weight.device:
+            EmbeddingFunction.bad_flag = torch.zeros(1, dtype=torch.int32, device=weight.device)
+        out = _empty((n, d), weight)
+        call("jova_embedding_fwd", P(weight), P(idx), n, d, weight.shape[0], P(out), P(EmbeddingFunction.bad_flag), stream())
+        ctx.idx, ctx.weight = idx, weight
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sink = _GradSink((ctx.weight,))
+        dout = _c(dout)
+        call("jova_embedding_bwd", P(dout), P(ctx.idx), ctx.idx.numel(), ctx.weight.shape[1], ctx.weight.shape[0],
+             P(sink.targets[0]), stream())
+        return sink.returns[0], None
+
+    @staticmethod
+    def raise_if_bad():
+        """One device->host read, off the hot loop: IndexError if any lookup so far had an id outside the table."""
+        f = EmbeddingFunction.bad_flag
+        if f is not None and int(f.item()):
+            f.zero_()
+            raise IndexError("index out of range in self (fingerprint id outside the embedding table)")
+
+
+class GnnUpdateFunction(torch.autograd.Function):
+    """x + (A @ hs) / (M - 1)  ('mean')  or  x + A @ hs  ('sum'): GraphNeuralNet.update_fingerprints after its Linear + ReLU
+    (jova/nn/models.py:364-372).  A is the block-diagonal adjacency the reference's collator hands over ([N, N] fp32, no
+    gradient): one fp32 MFMA GEMM forward, one (A^T) backward."""
+
+    @staticmethod
+    def forward(ctx, x, hs, A, M):
+        x, hs, A = _c(x), _c(hs), _c(A)
+        n, d = x.shape
+        if A.shape != (n, n):
+            raise RuntimeError("adjacency is %s for %d nodes" % (tuple(A.shape), n))
+        m = None if M is None else _c(M).reshape(-1)
+        tmp = _empty((n, d), x)
+        gemm(_addr(A), n, 1, _addr(hs), d, 1, _addr(tmp), d, n, d, n)
+        out = _empty((n, d), x)
+        call("jova_rowscale_add", P(x), P(tmp), P(m), n, d, P(out), stream())
+        ctx.A, ctx.m = A, m
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _c(dout)
+        n, d = dout.shape
+        g = dout
+        if ctx.m is not None:
+            g = torch.empty_like(dout)
+            call("jova_rowscale_add", None, P(dout), P(ctx.m), n, d, P(g), stream())
+        dhs = _empty((n, d), dout)
+        gemm(_addr(ctx.A), 1, n, _addr(g), d, 1, _addr(dhs), d, n, d, n)          # A^T g
+        return dout, dhs, None, None
+
+
 class MSELossFunction(torch.autograd.Function):
     """nn.MSELoss()(outputs * weights, target) (proj/dti/train_joint_attn.py:464-465)."""
 

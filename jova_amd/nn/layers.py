@@ -151,3 +151,17 @@ class Dropout(nn.Dropout):
         if not self.training or self.p == 0.:
             return x
         return F_.DropoutFunction.apply(x, self.p)
+
+
+class ElementwiseBatchNorm(nn.Module):
+    """BatchNorm over the last dimension of a tensor of any rank (jova/nn/layers.py:574-588): the tensor is viewed as
+    [-1, dim]; the statistics and the normalisation run on the HIP BatchNorm1d."""
+
+    def __init__(self, dim):
+        super(ElementwiseBatchNorm, self).__init__()
+        self.batch_norm = BatchNorm1d(dim)
+
+    def forward(self, x):
+        shape = x.shape
+        x = self.batch_norm(x.contiguous().view(-1, shape[-1]))
+        return x.view(*shape)

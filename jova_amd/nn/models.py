@@ -1,7 +1,8 @@
 """HIP-backed counterparts of the reference's hot-path models, same names / signatures / state-dict keys as
 /root/reference/jova/nn/models.py: GraphConvSequential :331-349, NonsatActivation :448-478, NwayForward :601-611,
 Prot2Vec :685-715 (+ _construct_embedding_indices :214-242), ProteinCNN / ProteinCNN2D :718-771,
-JointAttention :909-973, SegmentWiseLinear :976-1000, SegmentWiseResBlock :1003-1018.
+JointAttention :909-973, SegmentWiseLinear :976-1000, SegmentWiseResBlock :1003-1018, GraphNeuralNet /
+GraphNeuralNet2D :352-418.
 """
 import numpy as np
 import torch
@@ -73,6 +74,56 @@ class GraphConvSequential(nn.Sequential):
                 input[0] = module(input)
             k += 1
         return input[0]
+
+
+class GraphNeuralNet(nn.Module):
+    """The GNN view encoder (jova/nn/models.py:352-395; Tsubaki et al.): fingerprint embedding, `num_layers` updates
+    x <- x + A relu(W x + b) / (M - 1), then a per-molecule sum or mean.  Same constructor, parameters and state-dict
+    keys as the reference; embedding, Linear + ReLU, the A-product and the residual run on the HIP kernels."""
+
+    def __init__(self, num_fingerprints, embedding_dim, num_layers=3, update='mean', activation='relu'):
+        super(GraphNeuralNet, self).__init__()
+        if activation != 'relu':
+            raise NotImplementedError("the HIP GraphNeuralNet implements the reference's default 'relu'")
+        self.output = update
+        self.activation = get_activation_func(activation)
+        self.embed_fingerprint = nn.Embedding(num_fingerprints, int(embedding_dim))
+        self.W_gnn = nn.ModuleList([nn.Linear(embedding_dim, embedding_dim) for _ in range(num_layers)])
+
+    def _node_vectors(self, inputs):
+        fingerprints, adjacency_matrices, M, axis = inputs
+        F_._lib.require_gpu(fingerprints, adjacency_matrices, M)
+        x = F_.EmbeddingFunction.apply(self.embed_fingerprint.weight, fingerprints)
+        for lin in self.W_gnn:
+            hs = F_.LinearFunction.apply(x, lin.weight, lin.bias, True)
+            x = F_.GnnUpdateFunction.apply(x, hs, adjacency_matrices, None if self.output == 'sum' else M)
+        return x, [int(a) for a in axis]
+
+    def forward(self, inputs):
+        x, axis = self._node_vectors(inputs)
+        # per-molecule reduction through the zero-padded [A_max, B, d] image (sum over the segment axis; 'mean'
+        # divides by the molecule's size)
+        padded = F_.Gather2DFunction.apply(x, _AxisTopology(axis, x.device))
+        vec = padded.sum(0)
+        if self.output != 'sum':
+            vec = vec / torch.tensor(axis, dtype=vec.dtype, device=vec.device).unsqueeze(1)
+        return vec
+
+
+class GraphNeuralNet2D(GraphNeuralNet):
+    """-> [number of segments (A_max), batch size, dimension] (jova/nn/models.py:398-418): the node vectors of every
+    molecule, zero padded to the longest one, for the joint-attention block."""
+
+    def forward(self, inputs):
+        x, axis = self._node_vectors(inputs)
+        return F_.Gather2DFunction.apply(x, _AxisTopology(axis, x.device))
+
+
+class _AxisTopology(object):
+    def __init__(self, axis, device):
+        self.n_atoms_lst = list(axis)
+        off = np.concatenate([[0], np.cumsum(axis)]).astype(np.int32)
+        self.mol_off = torch.from_numpy(off).to(device, non_blocking=True)
 
 
 class NwayForward(nn.Module):

@@ -19,8 +19,9 @@ import torch.nn as nn
 
 from . import _lib
 from .nn import functional as F_
-from .nn.layers import BatchNorm1d, Dropout, GraphConvLayer, GraphGather2D, GraphPool, Linear, ReLU, Unsqueeze
-from .nn.models import GraphConvSequential, JointAttention, NwayForward, Prot2Vec, ProteinCNN2D
+from .nn.layers import (BatchNorm1d, Dropout, ElementwiseBatchNorm, GraphConvLayer, GraphGather2D, GraphPool, Linear, ReLU,
+                        Unsqueeze)
+from .nn.models import GraphConvSequential, GraphNeuralNet2D, JointAttention, NwayForward, Prot2Vec, ProteinCNN2D
 
 TUNED_DAVIS_HPARAMS = {
     # first row of proj/dti/soek_res/bayopt_search_integrated_view_attn_no_gan_pcnn2d_ecfp8_gconv_dti_2019_11_27__21_57_05_gp.csv
@@ -60,10 +61,18 @@ def create_prot_net(hparams, model_type, protein_profile):
     raise NotImplementedError("protein view %r is outside the hot path (SURVEY.md section 8)" % model_type)
 
 
+def create_gnn_net(hparams):
+    """proj/dti/train_joint_attn.py:177-184."""
+    dim = hparams["gnn"]["dim"]
+    gnn_model = GraphNeuralNet2D(num_fingerprints=hparams["gnn"]["fingerprint_size"], embedding_dim=dim,
+                                 num_layers=hparams["gnn"]["num_layers"])
+    return nn.Sequential(gnn_model, Linear(dim, dim), ElementwiseBatchNorm(dim), ReLU(), Dropout(hparams["dprob"]))
+
+
 def create_integrated_net(hparams, protein_profile, c_views=("ecfp8", "gconv"), attn_hook=None):
     """Same module tree as the reference builder: 0 = NwayForward, 1 = JointAttention, then the FC head.
     ``attn_hook`` is the callback the reference installs in explain mode (train_joint_attn.py:224-227)."""
-    creators = {"ecfp8": create_ecfp_net, "gconv": create_gconv_net}
+    creators = {"ecfp8": create_ecfp_net, "ecfp4": create_ecfp_net, "gconv": create_gconv_net, "gnn": create_gnn_net}
     views, seg_dims = [], []
     for cview in c_views:
         views.append(creators[cview](hparams))

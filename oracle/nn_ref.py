@@ -216,3 +216,15 @@ def dti_forward(p, batch, num_heads, n_pcnn_layers, n_lin):
 def mse_loss(outputs, weights, target):
     """train_joint_attn.py:464-465."""
     return ((outputs * weights - target) ** 2).mean()
+
+
+def gnn2d(fingerprints, A, M, axis, emb_w, ws, bs, update="mean"):
+    """GraphNeuralNet2D.forward (jova/nn/models.py:398-418 over :364-372): embedding, x <- x + A relu(W x + b) / (M - 1)
+    per layer ('sum': without the division), then split by molecule / zero pad / stack(1) -> [A_max, B, d]."""
+    x = emb_w[fingerprints]
+    for w, b in zip(ws, bs):
+        hs = torch.relu(x @ w.t() + b)
+        x = x + (A.to(x.dtype) @ hs if update == "sum" else (A.to(x.dtype) @ hs) / (M.to(x.dtype) - 1))
+    mols = torch.split(x, list(axis))
+    a_max = max(len(m) for m in mols)
+    return torch.stack([torch.nn.functional.pad(m, (0, 0, 0, a_max - len(m))) for m in mols], 1)

@@ -205,3 +205,24 @@ def test_segment_kats():
     assert out.tolist() == z["seg_sum_expect"].tolist()
     mx = [int(data[ids == s].max()) for s in range(4)]
     assert mx == z["seg_max_expect"].tolist()
+
+
+def test_gnn2d_oracle_vs_reference_golden():
+    """oracle/nn_ref.gnn2d against the reference's GraphNeuralNet2D (tests/golden/op_gnn2d.npz, tools/make_golden_gnn.py):
+    outputs and parameter gradients, 'mean' and 'sum' updates."""
+    import torch
+    from oracle import nn_ref as R
+    z = H.load("op_gnn2d")
+    n_fp, dim, layers = [int(v) for v in z["cfg"]]
+    for update in ("mean", "sum"):
+        emb = torch.from_numpy(z["sd.embed_fingerprint.weight"]).double().requires_grad_(True)
+        ws = [torch.from_numpy(z["sd.W_gnn.%d.weight" % k]).double().requires_grad_(True) for k in range(layers)]
+        bs = [torch.from_numpy(z["sd.W_gnn.%d.bias" % k]).double().requires_grad_(True) for k in range(layers)]
+        out = R.gnn2d(torch.from_numpy(z["fingerprints"]), torch.from_numpy(z["A"]), torch.from_numpy(z["M"]),
+                      z["axis"].tolist(), emb, ws, bs, update)
+        (out * torch.from_numpy(z[update + ".gout"]).double()).sum().backward()
+        H.assert_close(out.detach().float(), z[update + ".out"], tol=1e-5, what=update + " out")
+        H.assert_close(emb.grad.float(), z[update + ".grad.embed_fingerprint.weight"], tol=2e-5, what=update + " dE")
+        for k in range(layers):
+            H.assert_close(ws[k].grad.float(), z[update + ".grad.W_gnn.%d.weight" % k], tol=2e-5, what="dW%d" % k)
+            H.assert_close(bs[k].grad.float(), z[update + ".grad.W_gnn.%d.bias" % k], tol=2e-5, what="db%d" % k)
