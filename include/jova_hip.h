@@ -221,6 +221,12 @@ int jova_optim_step(int kind, float* params, const float* grads, float* state1, 
  * device->host read per batch */
 int jova_nonfinite_flag(const float* x, int64_t n, int* flag, void* stream);
 
+/* dst[r][c] (+)= src[r][c] inside the source's extent, 0 outside, for r < dst_rows, c < dst_cols (row strides ld_*): pads
+ * an operand of ProteinCNN's 242-wide layers (jova/nn/models.py:738-739, :768-771) to the aligned GEMM's 128-multiples,
+ * crops a result, or adds the [242, 242] block of a padded weight gradient to the real one (accumulate = 1). */
+int jova_copy2d(const float* src, int64_t src_rows, int src_cols, int64_t ld_src, float* dst, int64_t dst_rows,
+                int dst_cols, int64_t ld_dst, int accumulate, void* stream);
+
 /* ---- GraphNeuralNet / GraphNeuralNet2D (jova/nn/models.py:352-418), section 8(f3) ----------------------------- */
 /* nn.Embedding of the fingerprint ids: out[r][:] = weight[idx[r]][:]; an id outside [0, vocab) (nn.Embedding raises) sets
  * *bad_flag |= 1 and writes NaN.  Backward: dweight[idx[r]][:] += dout[r][:] (float atomics). */

@@ -47,6 +47,7 @@ _SIGS = {
     "jova_optim_step": "ipppp" + "qfffi" + "fffp",
     "jova_nonfinite_flag": "pqpp",
     "jova_dti_metrics": "pppi" + "dd" + "ppp",
+    "jova_copy2d": "pqiqpqiqip",
     "jova_embedding_fwd": "ppqiqppp", "jova_embedding_bwd": "ppqiqpp", "jova_rowscale_add": "pppqipp",
     "jova_relu_fwd": "pqpp",
     "jova_relu_bwd": "ppqpp",

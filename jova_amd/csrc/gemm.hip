@@ -632,7 +632,17 @@ extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
             const int parts = rem > 0 ? slots / rem : 1;
             const int max_parts = fa.nk_total / 8;                   // at least 8 k-tiles per part
             const int use = parts < max_parts ? parts : max_parts;
-            if (tiles > slots && use >= 2 && !relu && residual != C && ldc == N) {
+            // a lone product of a few tiles with a long K (the ecfp view projection: 128 x 512 x 1024 is four tiles):
+            // all of it is split along K, partial sums added onto the zeroed C, the bias rides with part 0
+            int few = fa.nk_total / 8;
+            if (few > slots / (tiles > 0 ? tiles : 1)) few = slots / (tiles > 0 ? tiles : 1);
+            if (tiles * 8 <= slots && few >= 2 && !relu && !residual && ldc == N) {
+                fa.full = 0;
+                fa.rem = tiles;
+                fa.per = (fa.nk_total + few - 1) / few;
+                fa.items = tiles * ((fa.nk_total + fa.per - 1) / fa.per);
+                JOVA_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(float), s));
+            } else if (tiles > slots && use >= 2 && !relu && residual != C && ldc == N) {
                 fa.full = tiles - rem;
                 fa.rem = rem;
                 fa.per = (fa.nk_total + use - 1) / use;

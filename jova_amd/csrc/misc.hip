@@ -393,6 +393,32 @@ extern "C" int jova_axpy(const float* x, float a, int64_t n, float* y, void* str
     return JOVA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ 2-D copy with zero fill
+// dst[r][c] (+)= (r < src_rows && c < src_cols) ? src[r][c] : 0 for r < dst_rows, c < dst_cols: pads an operand to the
+// aligned GEMM's 128-multiples (ProteinCNN's 242-wide layers), crops a result back, adds a padded weight gradient's block
+__global__ void copy2d_kernel(const float* __restrict__ src, long long src_rows, int src_cols, long long ld_src,
+                              float* __restrict__ dst, long long dst_rows, int dst_cols, long long ld_dst, int accumulate) {
+    const long long total = dst_rows * dst_cols;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / dst_cols;
+        const int c = (int)(e - r * dst_cols);
+        const float v = (r < src_rows && c < src_cols) ? src[r * ld_src + c] : 0.f;
+        float* d = dst + r * ld_dst + c;
+        *d = accumulate ? *d + v : v;
+    }
+}
+extern "C" int jova_copy2d(const float* src, int64_t src_rows, int src_cols, int64_t ld_src, float* dst, int64_t dst_rows,
+                           int dst_cols, int64_t ld_dst, int accumulate, void* stream) {
+    JOVA_CHECK_ARG(src_rows >= 0 && dst_rows >= 0 && src_cols >= 0 && dst_cols >= 1 && ld_src >= src_cols && ld_dst >= dst_cols &&
+                   (dst_rows == 0 || dst) && (src_rows == 0 || src_cols == 0 || src), "copy2d: bad argument");
+    if (dst_rows == 0) return JOVA_OK;
+    hipLaunchKernelGGL(copy2d_kernel, dim3(ew_blocks(dst_rows * dst_cols)), dim3(256), 0, (hipStream_t)stream, src,
+                       (long long)src_rows, src_cols, (long long)ld_src, dst, (long long)dst_rows, dst_cols,
+                       (long long)ld_dst, accumulate);
+    JOVA_CHECK_LAUNCH("copy2d");
+    return JOVA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ GraphNeuralNet pieces
 // nn.Embedding forward / backward (jova/nn/models.py:362, :376: the fingerprint embedding of GraphNeuralNet) and the
 // residual update x + (A hs) / (M - 1) of update_fingerprints (:364-372); 16 lanes per row, float4 when d % 4 == 0

@@ -541,6 +541,100 @@ class Prot2VecFunction(torch.autograd.Function):
         return sink.returns[0], None, None, None, None, None, None
 
 
+def copy2d(src, src_rows, src_cols, ld_src, dst, dst_rows, dst_cols, ld_dst, accumulate=False):
+    call("jova_copy2d", P(src), src_rows, src_cols, ld_src, P(dst), dst_rows, dst_cols, ld_dst, int(accumulate), stream())
+
+
+class ProteinCnnFunction(torch.autograd.Function):
+    """ProteinCNN / ProteinCNN2D's stack  x -> relu(W_k x + b_k)  (jova/nn/models.py:738-739, :768-771) as one autograd
+    node whose square layers run on the ALIGNED fp32 GEMM: the window * dim = 242 wide activations live in buffers padded
+    to 256 columns (zeros), the [242, 242] weights are padded per call into [256, 256] images (zero rows / columns keep
+    the padding at zero through every layer, forward and backward), so all six 23 k x 242 x 242 products of a Davis step
+    take the LDS-DMA kernel (110 instead of 38 TFLOP/s) at 12 % more arithmetic.  The last layer (242 -> dim) and its
+    gradients read the padded buffer with its row stride.  Used when rows % 128 == 0 (B = 128); otherwise the layers run
+    one by one on the generic form (LinearFunction)."""
+
+    @staticmethod
+    def usable(x, weights):
+        d = x.shape[-1]
+        m = x.numel() // max(d, 1)
+        dp = (d + 127) // 128 * 128
+        return (len(weights) >= 2 and m > 0 and m % 128 == 0 and d % 128 != 0 and dp * dp <= 1.3 * d * d and
+                all(tuple(w.shape) == (d, d) for w in weights[:-1]) and weights[-1].shape[1] == d)
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        ws, bs = params[0::2], params[1::2]
+        x = _c(x)
+        d = x.shape[-1]
+        m = x.numel() // d
+        dp = (d + 127) // 128 * 128
+        n_out = ws[-1].shape[0]
+        h = _empty((m, dp), x)
+        copy2d(x, m, d, d, h, m, dp, dp)
+        hs, wps = [h], []
+        for w, b in zip(ws[:-1], bs[:-1]):
+            wp, bp = _empty((dp, dp), x), _empty((dp,), x)
+            copy2d(w, d, d, d, wp, dp, dp, dp)
+            copy2d(b, 1, d, d, bp, 1, dp, dp)
+            nxt = _empty((m, dp), x)
+            linear_fwd(hs[-1], wp, bp, nxt, relu=True)
+            hs.append(nxt)
+            wps.append(wp)
+        out = _empty(x.shape[:-1] + (n_out,), x)
+        gemm(_addr(hs[-1]), dp, 1, _addr(ws[-1]), 1, d, _addr(out), n_out, m, n_out, d, bias=P(bs[-1]), relu=True)
+        ctx.params, ctx.hs, ctx.wps, ctx.out = params, hs, wps, out
+        ctx.dims = (m, d, dp, n_out, x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        params, hs, wps, out = ctx.params, ctx.hs, ctx.wps, ctx.out
+        m, d, dp, n_out, xshape = ctx.dims
+        ws = params[0::2]
+        sink = _GradSink(params)
+        dout = _c(dout).reshape(m, n_out)
+        dz = torch.empty_like(dout)
+        call("jova_relu_bwd", P(dout), P(out.view(m, n_out)), dout.numel(), P(dz), stream())
+        # last layer: dW [n_out, d] += dz^T h[:, :d];  db += colsum(dz);  dh = (dz W) masked by the ReLU of h, into padded rows
+        last = len(ws) - 1
+        sk = _splitk_for(n_out, d, m)
+        if sk > 1:
+            gemm(_addr(dz), 1, n_out, _addr(hs[-1]), dp, 1, _addr(sink.targets[2 * last]), d, n_out, d, m, splitk=sk)
+        else:
+            gemm(_addr(dz), 1, n_out, _addr(hs[-1]), dp, 1, _addr(sink.targets[2 * last]), d, n_out, d, m,
+                 residual=_addr(sink.targets[2 * last]), ldr=d)
+        call("jova_colsum_add", P(dz), m, n_out, n_out, P(sink.targets[2 * last + 1]), stream())
+        need_dx = ctx.needs_input_grad[0]
+        dh = None
+        if last > 0 or need_dx:
+            dh = _zeros((m, dp), dout)
+            if last > 0:
+                gemm(_addr(dz), n_out, 1, _addr(ws[-1]), d, 1, _addr(dh), dp, m, d, n_out, residual=_addr(hs[-1]), ldr=dp, relu=2)
+            else:
+                gemm(_addr(dz), n_out, 1, _addr(ws[-1]), d, 1, _addr(dh), dp, m, d, n_out)
+        for k in range(last - 1, -1, -1):
+            # h[k+1] = relu(h[k] Wp_k^T + bp_k); dh is already masked with h[k+1] > 0
+            dwp = _zeros((dp, dp), dout)
+            gemm(_addr(dh), 1, dp, _addr(hs[k]), dp, 1, _addr(dwp), dp, dp, dp, m, splitk=_splitk_for(dp, dp, m))
+            copy2d(dwp, d, d, dp, sink.targets[2 * k], d, d, d, accumulate=True)
+            call("jova_colsum_add", P(dh), m, d, dp, P(sink.targets[2 * k + 1]), stream())
+            if k > 0 or need_dx:
+                nxt = _empty((m, dp), dout)
+                if k > 0:
+                    linear_bwd_data(dh, wps[k], nxt, relu_mask=hs[k])
+                else:
+                    linear_bwd_data(dh, wps[k], nxt)
+                dh = nxt
+        dx = None
+        if need_dx:
+            dx = _empty((m, d), dout)
+            copy2d(dh, m, d, dp, dx, m, d, d)
+            dx = dx.view(xshape)
+        ctx.hs = ctx.wps = ctx.out = None
+        return (dx,) + tuple(sink.returns)
+
+
 # ------------------------------------------------------------------------------------------------------ joint attention
 class JointAttentionFunction(torch.autograd.Function):
     """JointAttention.forward (jova/nn/models.py:939-973) up to and including the view pooling, as one autograd node.

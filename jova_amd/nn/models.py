@@ -220,6 +220,11 @@ class ProteinCNN(nn.Module):
 
     def _convolve(self, prot_x):
         fused = isinstance(self.activation, ReLU)
+        if fused and prot_x.is_cuda and F_.ProteinCnnFunction.usable(prot_x, [k.weight for k in self.lin_kernels]):
+            params = []
+            for kernel in self.lin_kernels:
+                params += [kernel.weight, kernel.bias]
+            return F_.ProteinCnnFunction.apply(prot_x, *params)
         for kernel in self.lin_kernels:
             if fused:
                 prot_x = F_.LinearFunction.apply(prot_x, kernel.weight, kernel.bias, True)

@@ -51,6 +51,21 @@ def test_gemm_layouts(device, layout, shape):
     H.assert_close(C, want, tol=2e-6, what="gemm " + layout)
 
 
+@pytest.mark.parametrize("shape", [(128, 512, 1024), (256, 128, 4096), (128, 128, 256)])
+def test_gemm_few_tiles_long_k_is_split_with_bias(device, shape):
+    """The aligned form splits a product of a few tiles along K by itself (ecfp view projection, 128 x 512 x 1024):
+    partial sums onto a zeroed C, the bias added once; C starts as NaN, alpha rides along."""
+    from jova_amd.nn import functional as F_
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    want = ((a.double() @ b.double().t()) * 0.25 + bias.double()).float()
+    A, B, bias_d = a.to(device), b.to(device), bias.to(device)
+    C = torch.full((M, N), float("nan"), device=device)
+    F_.gemm(F_._addr(A), K, 1, F_._addr(B), 1, K, F_._addr(C), N, M, N, K, alpha=0.25, bias=F_.P(bias_d))
+    H.assert_close(C, want, tol=2e-6, what="few-tile split")
+
+
 @pytest.mark.parametrize("layout", ["kc", "rc"])
 def test_gemm_padded_rows_with_garbage_in_the_padding(device, layout):
     """Operands whose rows are padded to a multiple of 4 floats (the attention probabilities [S, S4]) take the 16-byte
@@ -322,6 +337,49 @@ def test_pcnn2d_vs_reference_golden(device):
     for i in range(3):
         H.assert_close(net.lin_kernels[i].weight.grad, z["grad.lin_kernels.%d.weight" % i], tol=1e-5, what="dW")
         H.assert_close(net.lin_kernels[i].bias.grad, z["grad.lin_kernels.%d.bias" % i], tol=1e-5, what="db")
+
+
+@pytest.mark.parametrize("layers", [2, 3])
+def test_pcnn2d_padded_aligned_form_vs_fp64_and_generic(device, layers):
+    """ProteinCNN2D at the tuned shape (dim 22 x window 11 = 242 columns, rows a multiple of 128) takes the padded form
+    (ProteinCnnFunction: 256-column buffers on the aligned GEMM); outputs and every gradient against fp64 torch, and
+    against the layer-by-layer generic form of the same module."""
+    from jova_amd.nn import functional as F_
+    from jova_amd.nn.models import ProteinCNN2D
+    torch.manual_seed(layers)
+    net = ProteinCNN2D(dim=22, window=11, num_layers=layers)
+    x = torch.randn(5, 128, 242)
+    gout = torch.randn(5, 128, 22)
+    ws = [k.weight.detach().double().requires_grad_(True) for k in net.lin_kernels]
+    bs = [k.bias.detach().double().requires_grad_(True) for k in net.lin_kernels]
+    xr = x.double().requires_grad_(True)
+    h = xr
+    for w, b in zip(ws, bs):
+        h = torch.relu(h @ w.t() + b)
+    (h * gout.double()).sum().backward()
+    net = net.to(device)
+    assert F_.ProteinCnnFunction.usable(x, [k.weight for k in net.lin_kernels])
+    res = {}
+    for form in ("padded", "generic"):
+        net.zero_grad()
+        xd = x.to(device).requires_grad_(True)
+        if form == "generic":
+            saved = F_.ProteinCnnFunction.usable
+            F_.ProteinCnnFunction.usable = staticmethod(lambda x_, w_: False)
+        try:
+            out = net(xd)
+            (out * gout.to(device)).sum().backward()
+        finally:
+            if form == "generic":
+                F_.ProteinCnnFunction.usable = saved
+        res[form] = (out.detach(), xd.grad, [k.weight.grad.clone() for k in net.lin_kernels],
+                     [k.bias.grad.clone() for k in net.lin_kernels])
+        H.assert_close(out, h.detach().float(), tol=1e-5, what=form + " out")
+        H.assert_close(xd.grad, xr.grad.float(), tol=1e-5, what=form + " dx")
+        for k in range(layers):
+            H.assert_close(res[form][2][k], ws[k].grad.float(), tol=1e-5, what=form + " dW%d" % k)
+            H.assert_close(res[form][3][k], bs[k].grad.float(), tol=1e-5, what=form + " db%d" % k)
+    assert res["padded"][0].grad_fn is None and res["padded"][0].shape == (5, 128, 22)
 
 
 # ------------------------------------------------------------------------------------------------ joint attention
