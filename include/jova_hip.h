@@ -239,6 +239,16 @@ int jova_embedding_bwd(const float* dout, const int64_t* idx, int64_t n, int d, 
 int jova_rowscale_add(const float* x_or_null, const float* y, const float* m_or_null, int64_t rows, int cols, float* out,
                       void* stream);
 
+/* ---- ProteinRNN (jova/nn/models.py:657-682): single-layer one-directional nn.LSTM, zero initial state, section 8(f3) --
+ * gx [T, B, 4H] = x W_ih^T + b_ih + b_hh for all steps (one jova_gemm_f32 by the caller; gate order i | f | g | o),
+ * w_hh [4H, H].  Forward writes h [T, B, H], the activated gates [T, B, 4H] and the cell states [T, B, H] (kept for the
+ * backward).  Backward takes dh [T, B, H] (gradient w.r.t. every h_t) and writes dgx [T, B, 4H], from which the caller
+ * forms dW_ih, dW_hh (against h shifted by one step), the biases and dx with GEMMs.  hidden <= 64. */
+int jova_lstm_fwd(const float* gx, const float* w_hh, int seq_len, int batch, int hidden, float* h_out, float* gates,
+                  float* c_out, void* stream);
+int jova_lstm_bwd(const float* dh, const float* w_hh, const float* gates, const float* c_seq, int seq_len, int batch,
+                  int hidden, float* dgx, void* stream);
+
 /* ---- evaluation metrics ---------------------------------------------------------------------------------------- */
 /* The metrics Jova.evaluate takes per evaluation batch (proj/dti/train_joint_attn.py:335-343 through
  * jova/metrics/all_metrics.py:80-104 and jova/metrics/cindex_measure.py:15-38, whose pair count is

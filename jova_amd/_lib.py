@@ -48,6 +48,7 @@ _SIGS = {
     "jova_nonfinite_flag": "pqpp",
     "jova_dti_metrics": "pppi" + "dd" + "ppp",
     "jova_copy2d": "pqiqpqiqip",
+    "jova_lstm_fwd": "ppiiipppp", "jova_lstm_bwd": "ppppiiipp",
     "jova_embedding_fwd": "ppqiqppp", "jova_embedding_bwd": "ppqiqpp", "jova_rowscale_add": "pppqipp",
     "jova_relu_fwd": "pqpp",
     "jova_relu_bwd": "ppqpp",

@@ -858,6 +858,58 @@ class GnnUpdateFunction(torch.autograd.Function):
         return dout, dhs, None, None
 
 
+class LstmFunction(torch.autograd.Function):
+    """Single-layer one-directional nn.LSTM with zero initial state followed by ReLU (ProteinRNN.forward,
+    jova/nn/models.py:672-682): x [T, B, in] -> relu(h) [T, B, H].  The input part of the gates is one GEMM over all steps,
+    the recurrence one persistent launch (jova_lstm_fwd); backward: jova_lstm_bwd for the gate gradients, then GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, relu):
+        x = _c(x)
+        T, B, K = x.shape
+        G, H = w_hh.shape
+        bias = b_ih + b_hh if b_ih is not None else None           # (4H floats; parameters are read, not written)
+        gx = _empty((T * B, G), x)
+        linear_fwd(x.view(T * B, K), w_ih, bias, gx)
+        h, gates, c = _empty((T, B, H), x), _empty((T, B, G), x), _empty((T, B, H), x)
+        call("jova_lstm_fwd", P(gx), P(w_hh), T, B, H, P(h), P(gates), P(c), stream())
+        out = h
+        if relu:
+            out = torch.empty_like(h)
+            call("jova_relu_fwd", P(h), h.numel(), P(out), stream())
+        ctx.params = (w_ih, w_hh, b_ih, b_hh)
+        ctx.saved = (x, h, gates, c, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, h, gates, c, out = ctx.saved
+        w_ih, w_hh, b_ih, b_hh = ctx.params
+        T, B, K = x.shape
+        G, H = w_hh.shape
+        dout = _c(dout)
+        dh = dout
+        if out is not None:
+            dh = torch.empty_like(dout)
+            call("jova_relu_bwd", P(dout), P(out), dout.numel(), P(dh), stream())
+        dgx = _empty((T, B, G), x)
+        call("jova_lstm_bwd", P(dh), P(w_hh), P(gates), P(c), T, B, H, P(dgx), stream())
+        sink = _GradSink(ctx.params)
+        dg2 = dgx.view(T * B, G)
+        linear_bwd_weight(dg2, x.view(T * B, K), sink.targets[0], sink.targets[2])
+        if sink.targets[3] is not None:
+            call("jova_colsum_add", P(dg2), T * B, G, G, P(sink.targets[3]), stream())
+        if T > 1:                                                   # dW_hh = sum_t dg_t^T h_{t-1}  (h_{-1} = 0)
+            linear_bwd_weight(dgx[1:].reshape((T - 1) * B, G), h[:T - 1].reshape((T - 1) * B, H), sink.targets[1], None)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty((T * B, K), x)
+            linear_bwd_data(dg2, w_ih, dx)
+            dx = dx.view(T, B, K)
+        ctx.saved = None
+        return dx, sink.returns[0], sink.returns[1], sink.returns[2], sink.returns[3], None
+
+
 class MSELossFunction(torch.autograd.Function):
     """nn.MSELoss()(outputs * weights, target) (proj/dti/train_joint_attn.py:464-465)."""
 

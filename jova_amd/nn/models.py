@@ -210,6 +210,35 @@ class Prot2Vec(nn.Module):
         return emb
 
 
+class ProteinRNN(nn.Module):
+    """LSTM protein encoder (jova/nn/models.py:657-682): same constructor and state-dict keys (``model.weight_ih_l0`` ...);
+    the HIP path covers what the DTI driver builds (train_joint_attn.py:77-86): one layer, one direction, hidden <= 64."""
+
+    def __init__(self, in_dim, hidden_dim, dropout, num_layers=1, bidrectional=False, activation='relu',
+                 batch_first=False):
+        super(ProteinRNN, self).__init__()
+        self.hidden_dim = int(hidden_dim)
+        self.num_layers = int(num_layers)
+        self.directions = max(1, int(bidrectional) + 1)
+        if self.num_layers != 1 or self.directions != 1:
+            raise NotImplementedError("the HIP ProteinRNN implements one layer, one direction (the DTI driver's use)")
+        if activation != 'relu':
+            raise NotImplementedError("the HIP ProteinRNN implements the reference's default 'relu'")
+        self.activation = get_activation_func(activation)
+        self.batch_first = batch_first
+        if num_layers == 1:
+            dropout = 0
+        self.model = nn.LSTM(input_size=int(in_dim), hidden_size=int(self.hidden_dim), num_layers=int(self.num_layers),
+                             batch_first=batch_first, dropout=dropout, bidirectional=bidrectional)
+
+    def forward(self, x):
+        if self.batch_first:
+            x = x.permute(1, 0, 2)
+        m = self.model
+        out = F_.LstmFunction.apply(x, m.weight_ih_l0, m.weight_hh_l0, m.bias_ih_l0, m.bias_hh_l0, True)
+        return out.permute(1, 0, 2) if self.batch_first else out
+
+
 class ProteinCNN(nn.Module):
     def __init__(self, dim, window, activation='relu', num_layers=2, pooling_dim=1):
         super(ProteinCNN, self).__init__()

@@ -21,7 +21,8 @@ from . import _lib
 from .nn import functional as F_
 from .nn.layers import (BatchNorm1d, Dropout, ElementwiseBatchNorm, GraphConvLayer, GraphGather2D, GraphPool, Linear, ReLU,
                         Unsqueeze)
-from .nn.models import GraphConvSequential, GraphNeuralNet2D, JointAttention, NwayForward, Prot2Vec, ProteinCNN2D
+from .nn.models import (GraphConvSequential, GraphNeuralNet2D, JointAttention, NwayForward, Prot2Vec, ProteinCNN2D,
+                        ProteinRNN)
 
 TUNED_DAVIS_HPARAMS = {
     # first row of proj/dti/soek_res/bayopt_search_integrated_view_attn_no_gan_pcnn2d_ecfp8_gconv_dti_2019_11_27__21_57_05_gp.csv
@@ -53,6 +54,12 @@ def create_prot_net(hparams, model_type, protein_profile):
                                       embedding_dim=hparams["prot"]["embedding_dim"], batch_first=False),
                              ProteinCNN2D(dim=hparams["prot"]["embedding_dim"], window=hparams["prot"]["window"],
                                           num_layers=hparams["prot"]["pcnn_num_layers"]))
+    if model_type == "rnn":                                         # train_joint_attn.py:77-86
+        return nn.Sequential(Prot2Vec(protein_profile=protein_profile, vocab_size=hparams["prot"]["vocab_size"],
+                                      embedding_dim=hparams["prot"]["embedding_dim"], batch_first=False),
+                             ProteinRNN(in_dim=hparams["prot"]["embedding_dim"] * hparams["prot"]["window"],
+                                        hidden_dim=hparams["prot"]["rnn_hidden_state_dim"], dropout=hparams["dprob"],
+                                        batch_first=False))
     if model_type == "p2v":
         return Prot2Vec(protein_profile=protein_profile, vocab_size=hparams["prot"]["vocab_size"],
                         embedding_dim=hparams["prot"]["embedding_dim"], batch_first=False)
@@ -83,6 +90,8 @@ def create_integrated_net(hparams, protein_profile, c_views=("ecfp8", "gconv"), 
             seg_dims.append(hparams["prot"]["psc_dim"])
         elif m_type == "p2v":
             seg_dims.append(hparams["prot"]["embedding_dim"] * hparams["prot"]["window"])
+        elif m_type == "rnn":
+            seg_dims.append(hparams["prot"]["rnn_hidden_state_dim"])
         else:
             seg_dims.append(hparams["prot"]["embedding_dim"])
     layers = [NwayForward(models=views),

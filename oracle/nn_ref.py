@@ -228,3 +228,20 @@ def gnn2d(fingerprints, A, M, axis, emb_w, ws, bs, update="mean"):
     mols = torch.split(x, list(axis))
     a_max = max(len(m) for m in mols)
     return torch.stack([torch.nn.functional.pad(m, (0, 0, 0, a_max - len(m))) for m in mols], 1)
+
+
+def protein_rnn(x, w_ih, w_hh, b_ih, b_hh):
+    """ProteinRNN.forward (jova/nn/models.py:672-682): one-layer, one-direction nn.LSTM from zero state (PyTorch gate order
+    i | f | g | o), then ReLU.  x [T, B, in] -> [T, B, H]."""
+    T, B, _ = x.shape
+    H = w_hh.shape[1]
+    h = torch.zeros(B, H, dtype=x.dtype)
+    c = torch.zeros(B, H, dtype=x.dtype)
+    outs = []
+    for t in range(T):
+        g = x[t] @ w_ih.t() + b_ih + h @ w_hh.t() + b_hh
+        i, f, gg, o = torch.sigmoid(g[:, :H]), torch.sigmoid(g[:, H:2 * H]), torch.tanh(g[:, 2 * H:3 * H]), torch.sigmoid(g[:, 3 * H:])
+        c = f * c + i * gg
+        h = o * torch.tanh(c)
+        outs.append(h)
+    return torch.relu(torch.stack(outs))
