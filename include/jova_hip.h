@@ -249,6 +249,16 @@ int jova_lstm_fwd(const float* gx, const float* w_hh, int seq_len, int batch, in
 int jova_lstm_bwd(const float* dh, const float* w_hh, const float* gates, const float* c_seq, int seq_len, int batch,
                   int hidden, float* dgx, void* stream);
 
+/* ---- Weave view (jova/nn/layers.py:72-232), section 8(f3) -------------------------------------------------------- */
+/* out[r][:] = src[idx[r]][:] (atom_features[atom_to_pair], layers.py:141-142; an index outside [0, m) yields NaN) and
+ * out[idx[r]][:] += src[r][:] (torch_scatter.scatter_add(src, index, dim=0), the function layers.py:135 and :191 call;
+ * float atomics, out is accumulated into). */
+int jova_gather_rows(const float* src, const int64_t* idx, int64_t n, int d, int64_t m, float* out, void* stream);
+int jova_scatter_add_rows(const float* src, const int64_t* idx, int64_t n, int d, int64_t m, float* out, void* stream);
+/* WeaveGather.gaussian_histogram (layers.py:198-207): x [n] -> out [n, 11]; backward dx [n] from dout [n, 11]. */
+int jova_gauss_hist_fwd(const float* x, int64_t n, float eps, float* out, void* stream);
+int jova_gauss_hist_bwd(const float* x, const float* dout, int64_t n, float eps, float* dx, void* stream);
+
 /* ---- evaluation metrics ---------------------------------------------------------------------------------------- */
 /* The metrics Jova.evaluate takes per evaluation batch (proj/dti/train_joint_attn.py:335-343 through
  * jova/metrics/all_metrics.py:80-104 and jova/metrics/cindex_measure.py:15-38, whose pair count is

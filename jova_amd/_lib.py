@@ -48,6 +48,8 @@ _SIGS = {
     "jova_nonfinite_flag": "pqpp",
     "jova_dti_metrics": "pppi" + "dd" + "ppp",
     "jova_copy2d": "pqiqpqiqip",
+    "jova_gather_rows": "ppqiqpp", "jova_scatter_add_rows": "ppqiqpp", "jova_gauss_hist_fwd": "pqfpp",
+    "jova_gauss_hist_bwd": "ppqfpp",
     "jova_lstm_fwd": "ppiiipppp", "jova_lstm_bwd": "ppppiiipp",
     "jova_embedding_fwd": "ppqiqppp", "jova_embedding_bwd": "ppqiqpp", "jova_rowscale_add": "pppqipp",
     "jova_relu_fwd": "pqpp",

@@ -487,6 +487,100 @@ extern "C" int jova_rowscale_add(const float* x_or_null, const float* y, const f
     return JOVA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ Weave pieces (section 8 f3)
+// out[r][:] = src[idx[r]][:]  (atom_features[atom_to_pair], jova/nn/layers.py:141-142) and its adjoint
+// out[idx[r]][:] += src[r][:]  (torch_scatter's scatter_add(src, index, dim=0), layers.py:135, :191)
+__global__ void gather_rows_kernel(const float* __restrict__ src, const long long* __restrict__ idx, long long n, int d,
+                                   long long m, float* __restrict__ out) {
+    const long long total = n * d;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / d;
+        const int c = (int)(e - r * d);
+        const long long k = idx[r];
+        out[e] = (k >= 0 && k < m) ? src[k * d + c] : __int_as_float(0x7fc00000);
+    }
+}
+__global__ void scatter_add_rows_kernel(const float* __restrict__ src, const long long* __restrict__ idx, long long n,
+                                        int d, long long m, float* __restrict__ out) {
+    const long long total = n * d;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / d;
+        const int c = (int)(e - r * d);
+        const long long k = idx[r];
+        if (k >= 0 && k < m) atomicAdd(&out[k * d + c], src[e]);
+    }
+}
+// WeaveGather.gaussian_histogram (layers.py:198-207): for the 11 fuzzy memberships (mean, std) v_k = log N(x; m_k, s_k) /
+// log N(m_k; m_k, s_k); out[.., 11 c + k] = (v_k + eps) / (sum_k v_k + eps)
+__constant__ float c_gh_mean[11] = {-1.645f, -1.080f, -0.739f, -0.468f, -0.228f, 0.f, 0.228f, 0.468f, 0.739f, 1.080f, 1.645f};
+__constant__ float c_gh_std[11] = {0.283f, 0.170f, 0.134f, 0.118f, 0.114f, 0.114f, 0.114f, 0.118f, 0.134f, 0.170f, 0.283f};
+__global__ void gauss_hist_kernel(const float* __restrict__ x, const float* __restrict__ dout, long long n, float eps,
+                                  float* __restrict__ out, float* __restrict__ dx) {
+    const float half_log_2pi = 0.91893853320467274178f;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const float xv = x[e];
+        float v[11], dvdx[11], tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float m = c_gh_mean[k], s = c_gh_std[k];
+            const float logs = logf(s);
+            const float dmax = -logs - half_log_2pi;                          // log_prob at the mean
+            const float lp = -((xv - m) * (xv - m)) / (2.f * s * s) - logs - half_log_2pi;
+            v[k] = lp / dmax;
+            dvdx[k] = -(xv - m) / (s * s) / dmax;
+            tot += v[k];
+        }
+        const float T = tot + eps;
+        if (out) {
+#pragma unroll
+            for (int k = 0; k < 11; ++k) out[e * 11 + k] = (v[k] + eps) / T;
+        }
+        if (dx) {
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) dot += dout[e * 11 + k] * (v[k] + eps);
+            float g = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) g += (dout[e * 11 + k] / T - dot / (T * T)) * dvdx[k];
+            dx[e] = g;
+        }
+    }
+}
+
+extern "C" int jova_gather_rows(const float* src, const int64_t* idx, int64_t n, int d, int64_t m, float* out, void* stream) {
+    JOVA_CHECK_ARG(n >= 0 && d >= 1 && m >= 0 && (n == 0 || (src && idx && out)), "gather_rows: bad argument");
+    if (n == 0) return JOVA_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_blocks(n * d)), dim3(256), 0, (hipStream_t)stream, src,
+                       (const long long*)idx, (long long)n, d, (long long)m, out);
+    JOVA_CHECK_LAUNCH("gather_rows");
+    return JOVA_OK;
+}
+extern "C" int jova_scatter_add_rows(const float* src, const int64_t* idx, int64_t n, int d, int64_t m, float* out,
+                                     void* stream) {
+    JOVA_CHECK_ARG(n >= 0 && d >= 1 && m >= 0 && (n == 0 || (src && idx && out)), "scatter_add_rows: bad argument");
+    if (n == 0) return JOVA_OK;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(ew_blocks(n * d)), dim3(256), 0, (hipStream_t)stream, src,
+                       (const long long*)idx, (long long)n, d, (long long)m, out);
+    JOVA_CHECK_LAUNCH("scatter_add_rows");
+    return JOVA_OK;
+}
+extern "C" int jova_gauss_hist_fwd(const float* x, int64_t n, float eps, float* out, void* stream) {
+    JOVA_CHECK_ARG(n >= 0 && (n == 0 || (x && out)), "gauss_hist_fwd: bad argument");
+    if (n == 0) return JOVA_OK;
+    hipLaunchKernelGGL(gauss_hist_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr,
+                       (long long)n, eps, out, (float*)nullptr);
+    JOVA_CHECK_LAUNCH("gauss_hist_fwd");
+    return JOVA_OK;
+}
+extern "C" int jova_gauss_hist_bwd(const float* x, const float* dout, int64_t n, float eps, float* dx, void* stream) {
+    JOVA_CHECK_ARG(n >= 0 && (n == 0 || (x && dout && dx)), "gauss_hist_bwd: bad argument");
+    if (n == 0) return JOVA_OK;
+    hipLaunchKernelGGL(gauss_hist_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, dout, (long long)n, eps,
+                       (float*)nullptr, dx);
+    JOVA_CHECK_LAUNCH("gauss_hist_bwd");
+    return JOVA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ error channel
 #include <stdarg.h>
 static thread_local char g_err[512] = "";

@@ -85,6 +85,32 @@ def process_gconv_view_data(X, prot_desc_dict, idx, cuda_prot):
     return mol_data, prots_tensor, prot_names, x_data
 
 
+def process_weave_view_data(X, prot_desc_dict, idx, cuda_prot):
+    """data.py:215-269 -> (mol_data, prots_tensor, prot_names, x_data) with
+    mol_data = [atom features float [N, F], pair features float [sum n^2, Fp], pair_split int32 [sum n^2] (the atom a pair
+    belongs to), atom_to_pair int64 [sum n^2, 2], atom_split int32 [N] (the molecule of an atom), n_atoms_list]."""
+    x_data = X[:, 0, idx]
+    mols = [pair[0] for pair in x_data]
+    n_atoms_list = [int(m.get_num_atoms()) for m in mols]
+    atom_feat = np.concatenate([np.asarray(m.get_atom_features(), dtype=np.float32) for m in mols], axis=0)
+    pair_feat = np.concatenate([np.asarray(m.get_pair_features(), dtype=np.float32).reshape(n * n, -1)
+                                for m, n in zip(mols, n_atoms_list)], axis=0)
+    atom_split = np.repeat(np.arange(len(mols), dtype=np.int32), n_atoms_list)
+    starts = np.concatenate([[0], np.cumsum(n_atoms_list)[:-1]])
+    a2p, psplit = [], []
+    for n, st in zip(n_atoms_list, starts):
+        r = np.repeat(np.arange(n), n) + st                       # C1.flatten(): the row atom of pair (i, j)
+        c = np.tile(np.arange(n), n) + st                         # C0.flatten()
+        a2p.append(np.stack([r, c], axis=1))
+        psplit.append(r)
+    atom_to_pair = np.concatenate(a2p, axis=0).astype(np.int64)
+    pair_split = np.concatenate(psplit).astype(np.int32)
+    mol_data = [cuda(torch.from_numpy(atom_feat)), cuda(torch.from_numpy(pair_feat)), cuda(torch.from_numpy(pair_split)),
+                cuda(torch.from_numpy(atom_to_pair)), cuda(torch.from_numpy(atom_split)), n_atoms_list]
+    prots_tensor, prot_names = _protein_tensor(x_data, prot_desc_dict, cuda_prot)
+    return mol_data, prots_tensor, prot_names, x_data
+
+
 def process_gnn_view_data(X, prot_desc_dict, idx, cuda_prot):
     """data.py:309-335 -> (mol_data, prots_tensor, prot_names, x_data) with
     mol_data = (fingerprints int64 [N], block-diagonal adjacency float [N, N], M float [N, 1], axis = atoms per molecule).
@@ -116,10 +142,10 @@ def process_gnn_view_data(X, prot_desc_dict, idx, cuda_prot):
 def batch_collator(batch, prot_desc_dict, spec, cuda_prot=True):
     """data.py:166-187 -> (batch_size, {view: ((view data ...), y [B] object array, w [B] object array)}).
     ``spec``: a dict {view name: active?} (iteration order = view index in the batch) or a single view name.
-    Views: ecfp4 / ecfp8 / gconv (the hot path) and gnn (section 8 f3); weave is not built."""
+    Views: ecfp4 / ecfp8 / gconv (the hot path), gnn and weave (section 8 f3)."""
     batch = _as_batch_array(batch)
     funcs = {"ecfp4": process_ecfp_view_data, "ecfp8": process_ecfp_view_data, "gconv": process_gconv_view_data,
-             "gnn": process_gnn_view_data}
+             "gnn": process_gnn_view_data, "weave": process_weave_view_data}
     active_views = [k for k in spec if spec[k]] if isinstance(spec, dict) else [spec]
     data = {}
     for i, v_name in enumerate(active_views):

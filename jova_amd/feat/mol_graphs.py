@@ -175,3 +175,36 @@ class MultiConvMol(object):
 
     def get_num_molecules(self):
         return self.num_mols
+
+
+class WeaveMol(object):
+    """Molecule struct of the weave view (jova/feat/mol_graphs.py:427-462): atom features [n, F], pair features [n, n, Fp]."""
+
+    def __init__(self, nodes, pairs, smiles=None):
+        self.nodes = nodes
+        self.pairs = pairs
+        self.smiles = smiles
+        self.num_atoms = self.nodes.shape[0]
+        self.n_features = self.nodes.shape[1]
+
+    def __eq__(self, other):
+        if isinstance(self, other.__class__):
+            assert self.smiles is not None
+            return self.smiles == other.smiles
+        return False
+
+    def __hash__(self):
+        assert self.smiles is not None
+        return hash(self.smiles)
+
+    def get_pair_features(self):
+        return self.pairs
+
+    def get_atom_features(self):
+        return self.nodes
+
+    def get_num_atoms(self):
+        return self.num_atoms
+
+    def get_num_features(self):
+        return self.n_features

@@ -910,6 +910,70 @@ class LstmFunction(torch.autograd.Function):
         return dx, sink.returns[0], sink.returns[1], sink.returns[2], sink.returns[3], None
 
 
+class RowGatherFunction(torch.autograd.Function):
+    """src[idx] over the first dimension (atom_features[atom_to_pair], jova/nn/layers.py:141-142); backward = scatter-add."""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        src = _c(src)
+        idx = idx.reshape(-1).to(torch.int64).contiguous()
+        m, d = src.shape
+        out = _empty((idx.numel(), d), src)
+        call("jova_gather_rows", P(src), P(idx), idx.numel(), d, m, P(out), stream())
+        ctx.idx, ctx.m = idx, m
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _c(dout)
+        dsrc = _zeros((ctx.m, dout.shape[1]), dout)
+        call("jova_scatter_add_rows", P(dout), P(ctx.idx), ctx.idx.numel(), dout.shape[1], ctx.m, P(dsrc), stream())
+        return dsrc, None
+
+
+class RowScatterAddFunction(torch.autograd.Function):
+    """torch_scatter.scatter_add(src, index, dim=0, fill_value=0) (the call of jova/nn/layers.py:135, :191): rows of src
+    summed into out[index]; out has max(index) + 1 rows unless ``m`` says otherwise.  Backward = gather."""
+
+    @staticmethod
+    def forward(ctx, src, idx, m):
+        src = _c(src)
+        idx = idx.reshape(-1).to(torch.int64).contiguous()
+        out = _zeros((m, src.shape[1]), src)
+        call("jova_scatter_add_rows", P(src), P(idx), idx.numel(), src.shape[1], m, P(out), stream())
+        ctx.idx, ctx.m = idx, m
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _c(dout)
+        dsrc = _empty((ctx.idx.numel(), dout.shape[1]), dout)
+        call("jova_gather_rows", P(dout), P(ctx.idx), ctx.idx.numel(), dout.shape[1], ctx.m, P(dsrc), stream())
+        return dsrc, None, None
+
+
+class GaussHistFunction(torch.autograd.Function):
+    """WeaveGather.gaussian_histogram (jova/nn/layers.py:198-207): [n, c] -> [n, 11 c]."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = _c(x)
+        n, c = x.shape
+        out = _empty((n, 11 * c), x)
+        call("jova_gauss_hist_fwd", P(x), x.numel(), float(eps), P(out), stream())
+        ctx.eps = float(eps)
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        dout = _c(dout)
+        dx = torch.empty_like(x)
+        call("jova_gauss_hist_bwd", P(x), P(dout), x.numel(), ctx.eps, P(dx), stream())
+        return dx, None
+
+
 class MSELossFunction(torch.autograd.Function):
     """nn.MSELoss()(outputs * weights, target) (proj/dti/train_joint_attn.py:464-465)."""
 

@@ -165,3 +165,129 @@ class ElementwiseBatchNorm(nn.Module):
         shape = x.shape
         x = self.batch_norm(x.contiguous().view(-1, shape[-1]))
         return x.view(*shape)
+
+
+# ------------------------------------------------------------------ Weave view (jova/nn/layers.py:72-262), section 8(f3)
+def _act(module, x):
+    return module(x) if module else x
+
+
+def _lin(layer, x, activation):
+    """Linear followed by the layer's activation; Linear + ReLU is one fused GEMM epilogue."""
+    if isinstance(activation, (ReLU, nn.ReLU)):
+        return F_.LinearFunction.apply(x, layer.weight, layer.bias, True)
+    return _act(activation, F_.LinearFunction.apply(x, layer.weight, layer.bias, False))
+
+
+class WeaveLayer(Layer):
+    """Weave convolution (layers.py:72-153): same constructor, parameters and forward contract.  The reference calls
+    torch_scatter.scatter_add, whose import it has commented out (layers.py:17, :135): its published semantics
+    (out[index[r]] += src[r]) are what jova_scatter_add_rows implements."""
+
+    def __init__(self, n_atom_input_feat=75, n_pair_input_feat=14, n_atom_output_feat=50, n_pair_output_feat=50,
+                 n_hidden_AA=50, n_hidden_PA=50, n_hidden_AP=50, n_hidden_PP=50, update_pair=True, activation='relu'):
+        super(WeaveLayer, self).__init__(activation)
+        self.update_pair = update_pair
+        self.n_hidden_AA, self.n_hidden_PA = n_hidden_AA, n_hidden_PA
+        self.n_hidden_AP, self.n_hidden_PP = n_hidden_AP, n_hidden_PP
+        self.n_hidden_A = n_hidden_AA + n_hidden_PA
+        self.n_hidden_P = n_hidden_AP + n_hidden_PP
+        self.n_atom_input_feat, self.n_pair_input_feat = n_atom_input_feat, n_pair_input_feat
+        self.n_atom_output_feat, self.n_pair_output_feat = n_atom_output_feat, n_pair_output_feat
+        self.linear_AA = Linear(self.n_atom_input_feat, self.n_hidden_AA)
+        self.linear_PA = Linear(self.n_pair_input_feat, self.n_hidden_PA)
+        self.linear_A = Linear(self.n_hidden_A, self.n_atom_output_feat)
+        if self.update_pair:
+            self.linear_AP = Linear(self.n_atom_input_feat * 2, self.n_hidden_AP)
+            self.linear_PP = Linear(self.n_pair_input_feat, self.n_hidden_PP)
+            self.linear_P = Linear(self.n_hidden_P, self.n_pair_output_feat)
+
+    def forward(self, input_data):
+        atom_features, pair_features, pair_split, atom_to_pair, _, _ = input_data
+        n_atoms = atom_features.shape[0]
+        AA = _lin(self.linear_AA, atom_features, self.activation)
+        PA = _lin(self.linear_PA, pair_features, self.activation)
+        PA = F_.RowScatterAddFunction.apply(PA, pair_split, n_atoms)
+        A = _lin(self.linear_A, torch.cat([AA, PA], dim=1), self.activation)
+        if self.update_pair:
+            f2 = 2 * self.n_atom_input_feat
+            ij = F_.RowGatherFunction.apply(atom_features, atom_to_pair).view(-1, f2)
+            ji = F_.RowGatherFunction.apply(atom_features, atom_to_pair.flip([1])).view(-1, f2)
+            AP_ij = _lin(self.linear_AP, ij, self.activation)
+            AP_ji = _lin(self.linear_AP, ji, self.activation)
+            PP = _lin(self.linear_PP, pair_features, self.activation)
+            P = _lin(self.linear_P, torch.cat([AP_ij + AP_ji, PP], dim=1), self.activation)
+        else:
+            P = pair_features
+        return A, P
+
+
+class WeaveGather(Layer):
+    """Final layer of the weave convolution (layers.py:156-207): gaussian expansion, per-molecule sum, Linear + activation."""
+
+    def __init__(self, conv_out_depth, n_depth=128, gaussian_expand=False, activation='tanh', epsilon=1e-7):
+        super(WeaveGather, self).__init__(activation)
+        self.n_depth = n_depth
+        self.conv_out_depth = conv_out_depth
+        self.gaussian_expand = gaussian_expand
+        self.epsilon = epsilon
+        self.gaussian_memberships = [(-1.645, 0.283), (-1.080, 0.170), (-0.739, 0.134), (-0.468, 0.118),
+                                     (-0.228, 0.114), (0., 0.114), (0.228, 0.114), (0.468, 0.118), (0.739, 0.134),
+                                     (1.080, 0.170), (1.645, 0.283)]
+        self.linear = Linear(self.conv_out_depth * len(self.gaussian_memberships), self.n_depth)
+
+    def gaussian_histogram(self, x):
+        return F_.GaussHistFunction.apply(x, self.epsilon)
+
+    def forward(self, input_data):
+        outputs, pair_features, atom_split, _ = input_data
+        if self.gaussian_expand:
+            outputs = self.gaussian_histogram(outputs)
+        n_mols = int(atom_split.max().item()) + 1 if atom_split.numel() else 0
+        output_molecules = F_.RowScatterAddFunction.apply(outputs, atom_split, n_mols)
+        if self.gaussian_expand:
+            output_molecules = _lin(self.linear, output_molecules, self.activation)
+        return output_molecules, pair_features
+
+
+class WeaveGather2D(WeaveGather):
+    """-> ([A_max, B, n_depth], pair features) (layers.py:210-232): per-atom gaussian expansion + Linear + activation, then the
+    molecules zero padded to the longest and stacked (jova_gather2d)."""
+
+    def __init__(self, *args, batch_first, **kwargs):
+        super(WeaveGather2D, self).__init__(*args, **kwargs)
+        self._batch_first = batch_first
+
+    def forward(self, input_data):
+        outputs, pair_features, atom_split, n_atoms_lst = input_data
+        if self.gaussian_expand:
+            outputs = self.gaussian_histogram(outputs)
+            outputs = _lin(self.linear, outputs, self.activation)
+        outputs = F_.Gather2DFunction.apply(outputs, _GatherOnlyTopology(n_atoms_lst, outputs.device))
+        if self._batch_first:
+            outputs = outputs.permute(1, 0, 2)
+        return outputs, pair_features
+
+
+class WeaveDropout(Layer):
+    def __init__(self, prob, update_pair):
+        super(WeaveDropout, self).__init__()
+        self.update_pair = update_pair
+        self.atom_dropout = Dropout(prob)
+        if update_pair:
+            self.pair_dropout = Dropout(prob)
+
+    def forward(self, atom_input, pair_input):
+        return self.atom_dropout(atom_input), self.pair_dropout(pair_input) if self.update_pair else pair_input
+
+
+class WeaveBatchNorm(Layer):
+    def __init__(self, atom_dim, update_pair, pair_dim, activation=None):
+        super(WeaveBatchNorm, self).__init__(activation)
+        self.update_pair = update_pair
+        self.a_batchnorm = BatchNorm1d(atom_dim)
+        if update_pair:
+            self.p_batchnorm = BatchNorm1d(pair_dim)
+
+    def forward(self, atom_input, pair_input):
+        return self.a_batchnorm(atom_input), self.p_batchnorm(pair_input) if self.update_pair else pair_input

@@ -9,7 +9,8 @@ import torch
 import torch.nn as nn
 
 from . import functional as F_
-from .layers import (BatchNorm1d, Dropout, GraphConvLayer, GraphGather, Linear, ReLU, get_activation_func)
+from .layers import (BatchNorm1d, Dropout, GraphConvLayer, GraphGather, Linear, ReLU, WeaveBatchNorm, WeaveDropout,
+                     WeaveGather, WeaveGather2D, WeaveLayer, get_activation_func)
 
 
 class NonsatActivation(nn.Module):
@@ -124,6 +125,60 @@ class _AxisTopology(object):
         self.n_atoms_lst = list(axis)
         off = np.concatenate([[0], np.cumsum(axis)]).astype(np.int32)
         self.mol_off = torch.from_numpy(off).to(device, non_blocking=True)
+
+
+def create_weave_layers(weave_args, update_pair):
+    """jova/nn/models.py:164-179."""
+    layers = []
+    for weave_arg in weave_args:
+        layers.append(WeaveLayer(*weave_arg.args))
+        if weave_arg.use_batch_norm:
+            layers.append(WeaveBatchNorm(atom_dim=weave_arg[2], pair_dim=weave_arg[3], update_pair=update_pair))
+        if weave_arg.dropout > 0:
+            layers.append(WeaveDropout(weave_arg.dropout, update_pair=update_pair))
+    return layers
+
+
+class WeaveSequential(nn.Sequential):
+    """jova/nn/models.py:282-307: threads (A, P) through the weave layers, hands [A, P, atom_split, n_atoms_lst] to the
+    gather layer."""
+
+    def forward(self, input):
+        input = list(input)
+        A = P = None
+        for module in self._modules.values():
+            if A is not None:
+                input[0] = A
+            if P is not None:
+                input[1] = P
+            if isinstance(module, (WeaveBatchNorm, WeaveDropout)):
+                A, P = module(A, P)
+            elif isinstance(module, WeaveGather):
+                return module([A, P, *input[4:]])
+            else:
+                A, P = module(input)
+        return A, P
+
+
+class WeaveModel(nn.Module):
+    """jova/nn/models.py:245-279."""
+
+    def __init__(self, weave_args, weave_gath_arg, update_pair=False, weave_type='1D', batch_first=False):
+        super(WeaveModel, self).__init__()
+        self.update_pair = update_pair
+        layers = create_weave_layers(weave_args, update_pair)
+        if weave_gath_arg:
+            if weave_type.lower() == '1d':
+                layers.append(WeaveGather(*weave_gath_arg.args))
+            else:
+                layers.append(WeaveGather2D(*weave_gath_arg, batch_first=batch_first))
+        self.weave_seq = WeaveSequential(*layers)
+
+    def forward(self, input, need_pair_feat=False):
+        output = self.weave_seq(input)
+        if need_pair_feat:
+            return output
+        return output[0]
 
 
 class NwayForward(nn.Module):

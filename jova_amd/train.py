@@ -68,6 +68,24 @@ def create_prot_net(hparams, model_type, protein_profile):
     raise NotImplementedError("protein view %r is outside the hot path (SURVEY.md section 8)" % model_type)
 
 
+def create_weave_net(hparams):
+    """proj/dti/train_joint_attn.py:119-152."""
+    from .nn.models import WeaveModel
+    from .utils.args import WeaveGatherArgs, WeaveLayerArgs
+    weave_args = (
+        WeaveLayerArgs(n_atom_input_feat=75, n_pair_input_feat=14, n_atom_output_feat=50, n_pair_output_feat=50,
+                       n_hidden_AA=50, n_hidden_PA=50, n_hidden_AP=50, n_hidden_PP=50,
+                       update_pair=hparams["weave"]["update_pairs"], activation='relu', batch_norm=True,
+                       dropout=hparams["dprob"]),
+        WeaveLayerArgs(n_atom_input_feat=50, n_pair_input_feat=14, n_atom_output_feat=hparams["weave"]["dim"],
+                       n_pair_output_feat=50, n_hidden_AA=50, n_hidden_PA=50, n_hidden_AP=50, n_hidden_PP=50,
+                       update_pair=hparams["weave"]["update_pairs"], batch_norm=True, dropout=hparams["dprob"],
+                       activation='relu'),
+    )
+    wg_args = WeaveGatherArgs(conv_out_depth=hparams["weave"]["dim"], gaussian_expand=True, n_depth=hparams["weave"]["dim"])
+    return nn.Sequential(WeaveModel(weave_args, weave_gath_arg=wg_args, weave_type='2D'))
+
+
 def create_gnn_net(hparams):
     """proj/dti/train_joint_attn.py:177-184."""
     dim = hparams["gnn"]["dim"]
@@ -79,7 +97,8 @@ def create_gnn_net(hparams):
 def create_integrated_net(hparams, protein_profile, c_views=("ecfp8", "gconv"), attn_hook=None):
     """Same module tree as the reference builder: 0 = NwayForward, 1 = JointAttention, then the FC head.
     ``attn_hook`` is the callback the reference installs in explain mode (train_joint_attn.py:224-227)."""
-    creators = {"ecfp8": create_ecfp_net, "ecfp4": create_ecfp_net, "gconv": create_gconv_net, "gnn": create_gnn_net}
+    creators = {"ecfp8": create_ecfp_net, "ecfp4": create_ecfp_net, "gconv": create_gconv_net, "gnn": create_gnn_net,
+                "weave": create_weave_net}
     views, seg_dims = [], []
     for cview in c_views:
         views.append(creators[cview](hparams))

@@ -245,3 +245,62 @@ def protein_rnn(x, w_ih, w_hh, b_ih, b_hh):
         h = o * torch.tanh(c)
         outs.append(h)
     return torch.relu(torch.stack(outs))
+
+
+_GH = [(-1.645, 0.283), (-1.080, 0.170), (-0.739, 0.134), (-0.468, 0.118), (-0.228, 0.114), (0., 0.114), (0.228, 0.114),
+       (0.468, 0.118), (0.739, 0.134), (1.080, 0.170), (1.645, 0.283)]
+
+
+def gaussian_histogram(x, eps=1e-7):
+    """WeaveGather.gaussian_histogram (jova/nn/layers.py:198-207): [n, c] -> [n, 11 c]."""
+    import math
+    outs = []
+    for m, s in _GH:
+        dmax = -math.log(s) - 0.5 * math.log(2 * math.pi)
+        lp = -((x - m) ** 2) / (2 * s * s) - math.log(s) - 0.5 * math.log(2 * math.pi)
+        outs.append(lp / dmax)
+    o = torch.stack(outs, dim=2)
+    o = (o + eps) / (o.sum(dim=2, keepdim=True) + eps)
+    return o.reshape(x.shape[0], -1)
+
+
+def _bn_train(x, g, b, eps=1e-5):
+    mu, var = x.mean(0), x.var(0, unbiased=False)
+    return (x - mu) / torch.sqrt(var + eps) * g + b
+
+
+def weave_model(p, atom_feat, pair_feat, pair_split, atom_to_pair, atom_split, n_atoms, n_layers, update_pair, two_d):
+    """WeaveModel.forward in training mode (jova/nn/models.py:245-307 over layers.py:72-262) for the builder's layout
+    [WeaveLayer, WeaveBatchNorm] * n_layers + WeaveGather(2D) with gaussian expansion, relu in the layers, tanh in the
+    gather; scatter_add = index_add over dim 0.  ``p``: state dict (prefix 'weave_seq.')."""
+    A, P = atom_feat, pair_feat
+    lin = lambda k, x: x @ p[k + ".weight"].t() + p[k + ".bias"]
+    idx = 0
+    ps, asp = pair_split.long(), atom_split.long()
+    for _ in range(n_layers):
+        pre = "weave_seq.%d." % idx
+        AA = torch.relu(lin(pre + "linear_AA", A))
+        PA = torch.relu(lin(pre + "linear_PA", P))
+        PA = torch.zeros(A.shape[0], PA.shape[1], dtype=A.dtype).index_add(0, ps, PA)
+        A_new = torch.relu(lin(pre + "linear_A", torch.cat([AA, PA], 1)))
+        if update_pair:
+            f2 = 2 * A.shape[1]
+            ij = torch.relu(lin(pre + "linear_AP", A[atom_to_pair].reshape(-1, f2)))
+            ji = torch.relu(lin(pre + "linear_AP", A[atom_to_pair.flip([1])].reshape(-1, f2)))
+            PP = torch.relu(lin(pre + "linear_PP", P))
+            P = torch.relu(lin(pre + "linear_P", torch.cat([ij + ji, PP], 1)))
+        A = A_new
+        bn = "weave_seq.%d." % (idx + 1)
+        A = _bn_train(A, p[bn + "a_batchnorm.weight"], p[bn + "a_batchnorm.bias"])
+        if update_pair:
+            P = _bn_train(P, p[bn + "p_batchnorm.weight"], p[bn + "p_batchnorm.bias"])
+        idx += 2
+    g = "weave_seq.%d." % idx
+    out = gaussian_histogram(A)
+    if two_d:
+        out = torch.tanh(lin(g + "linear", out))
+        mols = torch.split(out, list(n_atoms))
+        a_max = max(n_atoms)
+        return torch.stack([torch.nn.functional.pad(m, (0, 0, 0, a_max - len(m))) for m in mols], 1)
+    out = torch.zeros(len(n_atoms), out.shape[1], dtype=out.dtype).index_add(0, asp, out)
+    return torch.tanh(lin(g + "linear", out))
