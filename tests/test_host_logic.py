@@ -244,7 +244,7 @@ def test_batch_collator_reference_api_is_bit_exact(name):
     assert mols_tensor.dtype == torch.float32 and np.array_equal(mols_tensor.cpu().numpy(), np.array([e.bits for e in ecfps], np.float32))
     assert names2 == prot_names
     with pytest.raises(NotImplementedError):
-        batch_collator(batch, desc, "weave")
+        batch_collator(batch, desc, "no_such_view")
 
 
 def test_native_collate_rejects_bad_molecules():
