@@ -104,14 +104,16 @@ def launch_ranks(n):
 
 
 def measured_traffic():
-    """HBM-side bytes per launch of the probed GEMM from the committed PMC passes (profiles/r01_pmc_ffn1.json:
+    """HBM-side bytes per launch of the probed GEMM from the committed PMC passes (profiles/r02_pmc_ffn1.json, else r01:
     FETCH_SIZE / WRITE_SIZE collected in separate rocprofv3 --pmc runs of tools/one_gemm.py, gfx950 corrections applied
     as MI355X_MICROARCH.md prescribes).  It is quoted for the S = 279 launch those passes ran, not re-measured here."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_ffn1.json")) as f:
-            return int(json.load(f)["traffic_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
-        return None
+    for name in ("r02_pmc_ffn1.json", "r01_pmc_ffn1.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return int(json.load(f)["traffic_bytes_per_launch"])
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
 
 
 def cpu_baseline(pool, hp, batch_ids, state_dict, n_steps, threads):
@@ -274,7 +276,7 @@ def graph_stress(device, reps=20, full=True, row_order_lines=True):
               lambda: call("jova_graphconv_bwd", P(x1), 0, x1.shape[1], n, 75, 64, ds, adj, pw1, P(dz), None, pdw1, pdb1,
                            None, None, P(topo.sym_flag), dsh, P(dws), None, st),
               4 * (n * 64 + n * 75 + e) + 2 * 4 * 21 * 76 * 64,
-              kernels=("graphconv_bwd_dma_kernel<10, false, false, 4, false>", "graphconv_dw_fold_kernel"), launches=3,
+              kernels=("graphconv_bwd_split_kernel<10>", "graphconv_dw_fold_kernel"), launches=3,
               flops=4 * n * 75 * 64)
         # 64 -> 64: graphconv_bwd_wave_kernel (dW_self, dW_rel, G = dZ W_rel) + graphconv_bwd_dx_wave_kernel
         # (dx = dZ W_self + gathered G) + the scatter kernel that returns at once on a bond graph
@@ -452,7 +454,7 @@ def main():
     roofline = dict(kernel="gemm_f32_fast_kernel<K-contig,K-contig> (JointAttention FFN linear1, [S*B,512]x[512,2048]+bias+ReLU)",
                     bound="mfma", achieved=round(tfl, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(tfl / MFMA_F32_PEAK_TFLOPS, 4), traffic=measured_traffic(),
-                    traffic_note="bytes per launch at S=279 (profiles/r01_pmc_ffn1.json: 2*FETCH_SIZE + WRITE_SIZE, "
+                    traffic_note="bytes per launch at S=279 (profiles/r02_pmc_ffn1.json: 2*FETCH_SIZE + WRITE_SIZE, "
                                  "separate --pmc passes); algorithmic bytes of that launch 369.9e6",
                     launches=len(probe), avg_us=round(ms * 1e3 / max(len(probe), 1), 1))
     line = dict(metric="DTI training pairs/sec (fwd+bwd, whole node) + achieved HBM GB/s fraction",

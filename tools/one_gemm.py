@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from jova_amd.nn import functional as F_
 dev = torch.device('cuda:0')
 T, L, I = 279 * 128, 512, 2048

@@ -14,6 +14,14 @@ cd $R
 cp $O/kt/*/*kernel_stats.csv $O/bench_davis_kernel_stats.csv
 python tools/kt_groups.py $O/kt 1 40 > $O/bench_davis_kernel_groups.txt
 rm -rf $O/kt
-JOVA_DIAG_WATCHDOG=60 timeout -k 10 150 python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/diag_two_rank.py cpu staged nonsat devtensor devtensor_big > $O/diag_two_rank.log 2>&1
+cd /tmp
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pf_fetch -- python3 $R/tools/one_gemm.py ffn1 > /dev/null 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pf_write -- python3 $R/tools/one_gemm.py ffn1 > /dev/null 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pf_sq -- python3 $R/tools/one_gemm.py ffn1 > /dev/null 2>&1 || exit 1
+cd $R
+python tools/pmc_ffn_collect.py $O/pf_fetch $O/pf_write $O/pf_sq $O/r02_pmc_ffn1.json
+rm -rf $O/pf_fetch $O/pf_write $O/pf_sq
+bash tools/pmc_r02.sh
+JOVA_DIAG_WATCHDOG=60 timeout -k 10 150 python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/diag_two_rank.py cpu staged nonsat devtensor devtensor_big devtensor_loop > $O/diag_two_rank.log 2>&1
 echo "diag rc=$?" >> $O/diag_two_rank.log
 tail -5 $O/diag_two_rank.log
