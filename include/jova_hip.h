@@ -163,6 +163,12 @@ int jova_batchnorm_fwd(const float* x, int64_t n_rows, int c, const double* stat
 int jova_batchnorm_bwd(const float* x, const float* dy, const float* y_or_null, const float* mean_rstd,
                        const float* gamma, int64_t n_rows, int c, int relu_input_mask, float* dx, float* dgamma,
                        float* dbeta, double* sums_ws, void* stream);
+/* The two parameter gradients of an nn.Linear (jova/nn/models.py: every Linear of the path): dw[n_out, k_in] +=
+ * dy[rows, n_out]^T x[rows, k_in] and, when db is given, db[n_out] += column sums of dy.  splitk > 1 splits the rows over
+ * workgroups (dw accumulates atomically).  On the aligned GEMM form the column sums ride on the product's own reads of
+ * dy; otherwise jova_colsum_add runs behind it. */
+int jova_linear_bwd_weight(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, int64_t rows, int n_out, int k_in,
+                           float* dw, float* db_or_null, int splitk, void* stream);
 /* out[c] += column sums of x [n_rows, c] (bias gradients) */
 int jova_colsum_add(const float* x, int64_t n_rows, int c, int64_t ld, float* out, void* stream);
 

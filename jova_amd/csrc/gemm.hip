@@ -35,6 +35,7 @@ struct GemmArgs {
     int relu;
     int splitk;
     int vecA, vecB;
+    float* csum;          // aligned form, row-contiguous A only: csum[m] += sum_k A[m][k] (bias gradient of a dW product)
 };
 
 // Branch-free guarded loads: out-of-range elements read the (always valid) tensor base, so every global load is
@@ -401,6 +402,9 @@ gemm_f32_fast_kernel(FastArgs fa) {
         return true;
     };
 
+    // column sums of A (= the bias gradient when A is dY^T): the waves that hold column tile 0 add their A fragments up
+    float cs0 = 0.f, cs1 = 0.f;
+    bool do_cs = !A_KC && g.csum != nullptr && wn == 0 && item_n0(slot) == 0;
     f32x16 acc[2][2];
     auto zero_acc = [&]() {
 #pragma unroll
@@ -447,6 +451,10 @@ gemm_f32_fast_kernel(FastArgs fa) {
         }
     };
     auto mfma16 = [&](const Frag& f) {
+        if (!A_KC && do_cs) {
+            cs0 += (f.a0[0] + f.a0[1]) + (f.a0[2] + f.a0[3]);
+            cs1 += (f.a1[0] + f.a1[1]) + (f.a1[2] + f.a1[3]);
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[s], f.b0[s], acc[0][0], 0, 0, 0);
@@ -539,10 +547,19 @@ gemm_f32_fast_kernel(FastArgs fa) {
         compute(cur);
         if (--c_left == 0) {
             epilogue(c_item);
+            if (!A_KC && do_cs) {                    // lanes i and i + 32 hold the two k halves of rows wm + 2 i (+ 1)
+                const float t0 = cs0 + __shfl_xor(cs0, 32, 64), t1 = cs1 + __shfl_xor(cs1, 32, 64);
+                if (h == 0) {
+                    atomicAdd(&g.csum[item_m0(c_item) + wm + 2 * i], t0);
+                    atomicAdd(&g.csum[item_m0(c_item) + wm + 2 * i + 1], t1);
+                }
+                cs0 = cs1 = 0.f;
+            }
             ahead = false;
             c_item += nwg;
             if (c_item >= fa.items) return false;
             c_left = item_nk(c_item);
+            do_cs = !A_KC && g.csum != nullptr && wn == 0 && item_n0(c_item) == 0;
             zero_acc();
         }
         return true;
@@ -570,10 +587,13 @@ gemm_f32_fast_kernel(FastArgs fa) {
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
-                             float* C, int64_t ldc, int M, int N, int K, float alpha, const float* bias,
-                             const float* residual, int64_t ldr, int relu, int splitk, int nb1, int nb2, int64_t sA1,
-                             int64_t sA2, int64_t sB1, int64_t sB2, int64_t sC1, int64_t sC2, void* stream) {
+// csum / csum_done: the column sums of A, if the form that runs can add them up on the way (aligned form, A row-contiguous)
+static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+                     float* C, int64_t ldc, int M, int N, int K, float alpha, const float* bias,
+                     const float* residual, int64_t ldr, int relu, int splitk, int nb1, int nb2, int64_t sA1,
+                     int64_t sA2, int64_t sB1, int64_t sB2, int64_t sC1, int64_t sC2, void* stream, float* csum,
+                     bool* csum_done) {
+    if (csum_done) *csum_done = false;
     JOVA_CHECK_ARG(A && B && C, "gemm: null pointer");
     JOVA_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && nb1 >= 1 && nb2 >= 1, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
     JOVA_CHECK_ARG(sam == 1 || sak == 1, "gemm: A needs a unit stride (sam=%lld sak=%lld)", (long long)sam, (long long)sak);
@@ -587,6 +607,7 @@ extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
     g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.ldc = ldc; g.ldr = ldr;
     g.nb2 = nb2; g.sA1 = sA1; g.sA2 = sA2; g.sB1 = sB1; g.sB2 = sB2; g.sC1 = sC1; g.sC2 = sC2;
     g.alpha = alpha; g.relu = relu; g.splitk = splitk;
+    g.csum = nullptr;
     const bool a_kc = (sak == 1), b_kc = (sbk == 1);
     const int64_t a_ld = a_kc ? sam : sak, b_ld = b_kc ? sbn : sbk;
     // 16-byte loads need aligned quads, and a quad that straddles the end of the contiguous extent (K for a
@@ -610,6 +631,10 @@ extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
     const bool fast = fast_env && nb1 == 1 && nb2 == 1 && M % 128 == 0 && N % 128 == 0 && K % FBK == 0 && K > 0 && va &&
                       vb && aligned16(C) && (!residual || true);
     if (fast) {
+        if (csum && !a_kc) {
+            g.csum = csum;
+            if (csum_done) *csum_done = true;
+        }
         FastArgs fa;
         fa.g = g;
         fa.ntm = M / 128;
@@ -728,5 +753,34 @@ extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
     else if (!a_kc && b_kc) GEMM_VEC(false, true);
     else GEMM_VEC(false, false);
     JOVA_CHECK_LAUNCH("gemm_f32");
+    return JOVA_OK;
+}
+
+extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+                             float* C, int64_t ldc, int M, int N, int K, float alpha, const float* bias,
+                             const float* residual, int64_t ldr, int relu, int splitk, int nb1, int nb2, int64_t sA1,
+                             int64_t sA2, int64_t sB1, int64_t sB2, int64_t sC1, int64_t sC2, void* stream) {
+    return gemm_impl(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha, bias, residual, ldr, relu, splitk, nb1, nb2, sA1,
+                     sA2, sB1, sB2, sC1, sC2, stream, nullptr, nullptr);
+}
+
+// dw[n_out, k_in] += dy[rows, n_out]^T x[rows, k_in];  db[n_out] += column sums of dy  (the two gradients of an nn.Linear).
+// On the aligned form the column sums are added up from the A fragments the product reads anyway; otherwise a
+// separate pass over dy does it.
+extern "C" int jova_linear_bwd_weight(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, int64_t rows, int n_out,
+                                      int k_in, float* dw, float* db_or_null, int splitk, void* stream) {
+    JOVA_CHECK_ARG(dy && x && dw && rows >= 0 && n_out >= 1 && k_in >= 1 && ld_dy >= n_out && ld_x >= k_in && splitk >= 1 &&
+                   rows < (1ll << 31), "linear_bwd_weight: bad argument");
+    if (rows == 0) return JOVA_OK;
+    bool done = false;
+    int rc;
+    if (splitk > 1)
+        rc = gemm_impl(dy, 1, ld_dy, x, ld_x, 1, dw, k_in, n_out, k_in, (int)rows, 1.f, nullptr, nullptr, 0, 0, splitk, 1, 1,
+                       0, 0, 0, 0, 0, 0, stream, db_or_null, &done);
+    else
+        rc = gemm_impl(dy, 1, ld_dy, x, ld_x, 1, dw, k_in, n_out, k_in, (int)rows, 1.f, nullptr, dw, k_in, 0, 1, 1, 1, 0, 0,
+                       0, 0, 0, 0, stream, db_or_null, &done);
+    if (rc != JOVA_OK) return rc;
+    if (db_or_null && !done) return jova_colsum_add(dy, rows, n_out, ld_dy, db_or_null, stream);
     return JOVA_OK;
 }

@@ -353,13 +353,10 @@ def linear_bwd_weight(dy2d, x2d, dw, db):
     M, N = dy2d.shape
     K = x2d.shape[1]
     if dw is not None:
-        sk = _splitk_for(N, K, M)
-        # split-K adds atomically into dw (accumulate semantics); a single split must accumulate too -> residual = dw
-        if sk > 1:
-            gemm(_addr(dy2d), 1, N, _addr(x2d), K, 1, _addr(dw), K, N, K, M, splitk=sk)
-        else:
-            gemm(_addr(dy2d), 1, N, _addr(x2d), K, 1, _addr(dw), K, N, K, M, residual=_addr(dw), ldr=K)
-    if db is not None:
+        # (split-K adds atomically into dw; a single split accumulates through the residual; the bias gradient rides on
+        # the product's reads of dy when the aligned form runs)
+        call("jova_linear_bwd_weight", P(dy2d), N, P(x2d), K, M, N, K, P(dw), P(db), _splitk_for(N, K, M), stream())
+    elif db is not None:
         call("jova_colsum_add", P(dy2d), M, N, N, P(db), stream())
 
 
@@ -615,10 +612,10 @@ class ProteinCnnFunction(torch.autograd.Function):
                 gemm(_addr(dz), n_out, 1, _addr(ws[-1]), d, 1, _addr(dh), dp, m, d, n_out)
         for k in range(last - 1, -1, -1):
             # h[k+1] = relu(h[k] Wp_k^T + bp_k); dh is already masked with h[k+1] > 0
-            dwp = _zeros((dp, dp), dout)
-            gemm(_addr(dh), 1, dp, _addr(hs[k]), dp, 1, _addr(dwp), dp, dp, dp, m, splitk=_splitk_for(dp, dp, m))
+            dwp, dbp = _zeros((dp, dp), dout), _zeros((dp,), dout)
+            call("jova_linear_bwd_weight", P(dh), dp, P(hs[k]), dp, m, dp, dp, P(dwp), P(dbp), _splitk_for(dp, dp, m), stream())
             copy2d(dwp, d, d, dp, sink.targets[2 * k], d, d, d, accumulate=True)
-            call("jova_colsum_add", P(dh), m, d, dp, P(sink.targets[2 * k + 1]), stream())
+            copy2d(dbp, 1, d, dp, sink.targets[2 * k + 1], 1, d, d, accumulate=True)
             if k > 0 or need_dx:
                 nxt = _empty((m, dp), dout)
                 if k > 0:

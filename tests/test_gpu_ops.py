@@ -66,6 +66,26 @@ def test_gemm_few_tiles_long_k_is_split_with_bias(device, shape):
     H.assert_close(C, want, tol=2e-6, what="few-tile split")
 
 
+@pytest.mark.parametrize("shape", [(3840, 2048, 512), (1280, 512, 512), (256, 128, 128), (640, 242, 242), (77, 22, 512)])
+def test_linear_bwd_weight_fuses_the_bias_gradient(device, shape):
+    """jova_linear_bwd_weight: dw += dy^T x and db += colsum(dy), both ACCUMULATING, on the aligned form (bias gradient
+    summed from the product's own A fragments, with and without split-K) and on the generic form (separate pass)."""
+    from jova_amd.nn import functional as F_
+    rows, n_out, k_in = shape
+    g = torch.Generator().manual_seed(rows + n_out)
+    dy, x = torch.randn(rows, n_out, generator=g), torch.randn(rows, k_in, generator=g)
+    dw0, db0 = torch.randn(n_out, k_in, generator=g), torch.randn(n_out, generator=g)
+    want_dw = (dw0.double() + dy.double().t() @ x.double()).float()
+    want_db = (db0.double() + dy.double().sum(0)).float()
+    dyd, xd, dw, db = dy.to(device), x.to(device), dw0.to(device), db0.to(device)
+    F_.linear_bwd_weight(dyd, xd, dw, db)
+    H.assert_close(dw, want_dw, tol=2e-6, what="dw")
+    H.assert_close(db, want_db, tol=2e-6, what="db")
+    dw2 = dw0.to(device)
+    F_.linear_bwd_weight(dyd, xd, dw2, None)                    # without a bias
+    H.assert_close(dw2, want_dw, tol=2e-6, what="dw (no bias)")
+
+
 @pytest.mark.parametrize("layout", ["kc", "rc"])
 def test_gemm_padded_rows_with_garbage_in_the_padding(device, layout):
     """Operands whose rows are padded to a multiple of 4 floats (the attention probabilities [S, S4]) take the 16-byte
