@@ -37,6 +37,16 @@ void jova_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+// Zero fill as a KERNEL on the stream (rows of row_bytes at a pitch; bytes and pitch multiples of 4).  The library does
+// not use hipMemsetAsync: as memset nodes of a captured hipGraph small memsets did not take effect on every replay on
+// this ROCm (the persistent nonsat kernel then met stale barrier words), a kernel node always does.
+int jova_zero_fill(void* p, size_t row_bytes, size_t rows, size_t pitch_bytes, hipStream_t s);
+#define JOVA_ZERO(ptr, bytes, stream)                                                               \
+    do {                                                                                            \
+        int rc_ = jova_zero_fill((ptr), (size_t)(bytes), 1, (size_t)(bytes), (stream));             \
+        if (rc_ != JOVA_OK) return rc_;                                                             \
+    } while (0)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

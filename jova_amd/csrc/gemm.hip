@@ -666,14 +666,14 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
                 fa.rem = tiles;
                 fa.per = (fa.nk_total + few - 1) / few;
                 fa.items = tiles * ((fa.nk_total + fa.per - 1) / fa.per);
-                JOVA_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(float), s));
+                JOVA_ZERO(C, (size_t)M * ldc * sizeof(float), s);
             } else if (tiles > slots && use >= 2 && !relu && residual != C && ldc == N) {
                 fa.full = tiles - rem;
                 fa.rem = rem;
                 fa.per = (fa.nk_total + use - 1) / use;
                 fa.items = fa.full + rem * ((fa.nk_total + fa.per - 1) / fa.per);
                 const long long row0 = (long long)(fa.full / fa.ntn) * 128;
-                JOVA_CHECK_HIP(hipMemsetAsync(C + row0 * ldc, 0, (size_t)(M - row0) * ldc * sizeof(float), s));
+                JOVA_ZERO(C + row0 * ldc, (size_t)(M - row0) * ldc * sizeof(float), s);
             }
         }
         const int nwg = fa.items < slots ? fa.items : slots;
@@ -721,7 +721,10 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
         if (sk > K / 64) sk = K / 64;
         if (sk > 32) sk = 32;
         if (sk >= 2) {
-            JOVA_CHECK_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s));
+            {
+                const int rcz = jova_zero_fill(C, (size_t)N * sizeof(float), (size_t)M, (size_t)ldc * sizeof(float), s);
+                if (rcz != JOVA_OK) return rcz;
+            }
             g.splitk = sk;
             gz = sk;
         }

@@ -3350,7 +3350,7 @@ extern "C" int jova_graphconv_fwd(const void* atoms, int atoms_is_i64, int64_t l
     // (an empty batch has no per-atom buffers: those pointers may be null when n_atoms == 0)
     JOVA_CHECK_ARG(deg_slice && adj && weight && bias && packed_ws && (n_atoms == 0 || (atoms && out)), "graphconv_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (bn_stats) JOVA_CHECK_HIP(hipMemsetAsync(bn_stats, 0, sizeof(double) * 2 * f_out, s));
+    if (bn_stats) JOVA_ZERO(bn_stats, sizeof(double) * 2 * f_out, s);
     if (n_atoms == 0) return JOVA_OK;
     GcParams P;
     fill_params(P, adj, weight, bias);
@@ -3468,7 +3468,7 @@ extern "C" int jova_graphconv_bwd(const void* atoms, int atoms_is_i64, int64_t l
         (!dx_or_null || (kg == 8 && (f_in & 3) == 0)) && !getenv("JOVA_GRAPHCONV_NO_DMA")) {
         // weight rows that are not whole 128-byte lines: accumulate in the aligned scratch image, fold afterwards
         float* dwp = (dw_scratch_or_null && (f_in & 31) != 0 && !getenv("JOVA_BWD_NO_DWP")) ? dw_scratch_or_null : nullptr;
-        if (dwp) JOVA_CHECK_HIP(hipMemsetAsync(dwp, 0, sizeof(float) * 21 * 64 * DWP_LD, s));
+        if (dwp) JOVA_ZERO(dwp, sizeof(float) * 21 * 64 * DWP_LD, s);
         // wave-private form (see graphconv_bwd_wave_kernel): dZ handed in, host copy of the bucket table at hand
         // 80-float rows, dW only: waves specialised by matrix (graphconv_bwd_split_kernel)
         if (kg == 10 && !dx_or_null && !y_or_null && deg_slice_host && n_atoms * ld_atoms < (1ll << 30) &&
@@ -3702,7 +3702,7 @@ extern "C" int jova_graphpool_bwd(const float* dy, const uint8_t* argmax, int64_
         return JOVA_OK;
     }
     // the scatter path accumulates into dx; zeroing is harmless for the gather path (it overwrites)
-    JOVA_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)n_atoms * f, s));
+    JOVA_ZERO(dx, sizeof(float) * (size_t)n_atoms * f, s);
     hipLaunchKernelGGL(graphpool_bwd_kernel, dim3(cdiv(n_atoms, 4)), dim3(256), 0, s, dy, argmax, (int)n_atoms, f,
                        (const long long*)deg_slice, P, dx, sym_flag);
     JOVA_CHECK_LAUNCH("graphpool_bwd");
@@ -3763,6 +3763,12 @@ static int nonsat_block_cap(int* cap) {
     return JOVA_OK;
 }
 
+__global__ void nonsat_init_kernel(int* __restrict__ ws_words, int n_words, int* __restrict__ n_eval) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_words) ws_words[e] = 0;
+    if (e < 3) n_eval[e] = 0;
+}
+
 static int nonsat_launch(const float* x, int64_t n, float ep, int max_iter, float* out, float* dfac, int* n_eval_dev,
                          void* workspace, hipStream_t s) {
     JOVA_CHECK_HIP(num_cu_cached());
@@ -3771,8 +3777,11 @@ static int nonsat_launch(const float* x, int64_t n, float ep, int max_iter, floa
     double* partial = (double*)((char*)workspace + 64);
     float* ya = (float*)((char*)workspace + 64 + sizeof(double) * 2 * NS_MAX_BLOCKS);
     float* yb = ya + n;
-    JOVA_CHECK_HIP(hipMemsetAsync(workspace, 0, 64 + sizeof(double) * 2 * NS_MAX_BLOCKS, s));
-    JOVA_CHECK_HIP(hipMemsetAsync(n_eval_dev, 0, 3 * sizeof(int), s));
+    // control words, partials and the result words start at zero: ONE small kernel (two memsets before; as memset nodes
+    // of a captured hipGraph they did not take effect on every replay -- tests/test_gpu_ops.py, capture test)
+    hipLaunchKernelGGL(nonsat_init_kernel, dim3(cdiv(16 + 4 * NS_MAX_BLOCKS, 256)), dim3(256), 0, s, (int*)workspace,
+                       16 + 4 * NS_MAX_BLOCKS, n_eval_dev);
+    JOVA_CHECK_LAUNCH("nonsat_init");
     if (n == 0) return JOVA_OK;
     // one workgroup per CU at most, capped by the occupancy query: every workgroup is resident at once, which the
     // in-kernel barrier needs (a plain launch: the call stays capturable into a hipGraph)

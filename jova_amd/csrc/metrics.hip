@@ -123,7 +123,7 @@ extern "C" int jova_dti_metrics(const float* y_true, const float* y_pred, const 
     JOVA_CHECK_ARG(ws16 && out6 && n >= 0 && (n == 0 || (y_true && y_pred)), "dti_metrics: bad argument");
     JOVA_CHECK_ARG(n <= (1 << 20), "dti_metrics: more than 2^20 samples");
     hipStream_t s = (hipStream_t)stream;
-    JOVA_CHECK_HIP(hipMemsetAsync(ws16, 0, 16 * sizeof(double), s));
+    JOVA_ZERO(ws16, 16 * sizeof(double), s);
     if (n > 0) {
         const int nt = (n + MT - 1) / MT;
         hipLaunchKernelGGL(metrics_sums_kernel, dim3(nt < 1024 ? nt : 1024), dim3(MT), 0, s, y_true, y_pred, w_or_null, n,

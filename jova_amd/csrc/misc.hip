@@ -581,6 +581,32 @@ extern "C" int jova_gauss_hist_bwd(const float* x, const float* dout, int64_t n,
     return JOVA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ zero fill (see common.h)
+__global__ void zero_words_kernel(unsigned* __restrict__ p, long long row_words, long long rows, long long pitch_words) {
+    const long long total = row_words * rows;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x)
+        p[(e / row_words) * pitch_words + e % row_words] = 0u;
+}
+__global__ void zero_quads_kernel(uint4* __restrict__ p, long long n_quads) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n_quads; e += (long long)gridDim.x * blockDim.x)
+        p[e] = make_uint4(0u, 0u, 0u, 0u);
+}
+int jova_zero_fill(void* p, size_t row_bytes, size_t rows, size_t pitch_bytes, hipStream_t s) {
+    JOVA_CHECK_ARG((row_bytes & 3) == 0 && (pitch_bytes & 3) == 0 && pitch_bytes >= row_bytes && (p || row_bytes * rows == 0),
+                   "zero_fill: bad argument");
+    if (row_bytes == 0 || rows == 0) return JOVA_OK;
+    if ((rows == 1 || pitch_bytes == row_bytes) && ((row_bytes * rows) & 15) == 0 && (((uintptr_t)p) & 15) == 0) {
+        const long long nq = (long long)(row_bytes * rows / 16);
+        hipLaunchKernelGGL(zero_quads_kernel, dim3(ew_blocks(nq)), dim3(256), 0, s, (uint4*)p, nq);
+    } else {
+        const long long rw = (long long)(row_bytes / 4);
+        hipLaunchKernelGGL(zero_words_kernel, dim3(ew_blocks(rw * (long long)rows)), dim3(256), 0, s, (unsigned*)p, rw,
+                           (long long)rows, (long long)(pitch_bytes / 4));
+    }
+    JOVA_CHECK_LAUNCH("zero_fill");
+    return JOVA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ error channel
 #include <stdarg.h>
 static thread_local char g_err[512] = "";

@@ -414,7 +414,7 @@ dropout_v4_kernel(const float* __restrict__ x, long long quads, float p, unsigne
 extern "C" int jova_colstats(const float* x, int64_t n_rows, int c, double* stats, void* stream) {
     JOVA_CHECK_ARG(x && stats && n_rows >= 0 && c >= 1, "colstats: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    JOVA_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * c, s));
+    JOVA_ZERO(stats, sizeof(double) * 2 * c, s);
     if (n_rows == 0) return JOVA_OK;
     dim3 grid;
     int rpb;
@@ -461,7 +461,7 @@ extern "C" int jova_batchnorm_bwd(const float* x, const float* dy, const float* 
     JOVA_CHECK_ARG(x && dy && mean_rstd && gamma && dx && dgamma && dbeta && sums_ws && n_rows >= 1 && c >= 1,
                    "batchnorm_bwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    JOVA_CHECK_HIP(hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * c, s));
+    JOVA_ZERO(sums_ws, sizeof(double) * 2 * c, s);
     dim3 grid;
     int rpb;
     colreduce_grid(n_rows, c, grid, rpb);

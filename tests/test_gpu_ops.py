@@ -943,3 +943,55 @@ def test_collator_host_images_equal_device_kernels(device, shape, n_mols):
     flag = torch.zeros(1, dtype=torch.int32, device=device)
     F_.call("jova_adj_symmetry", n, F_.P(topo.deg_slice), topo.adj_ptrs, F_.P(flag), F_.stream())
     assert int(flag.item()) == 1 == int(topo.sym_flag.item())
+
+
+def test_entry_points_capture_into_a_hip_graph(device):
+    """the entry points only enqueue kernels / memsets on the given stream.  Three of them (an
+    aligned GEMM with its in-stream memset, the graph pooling, the allocation-free nonsat) are captured into ONE HIP
+    graph, together with a BatchNorm statistics pass (whose scratch is zeroed in-stream); three replays on changed inputs must
+    equal the eager calls.  (First version of this test: the nonsat call's two small hipMemsetAsync did not take effect on
+    every replay as memset nodes -- stale barrier words, NaN-filled output; the library now zeroes with kernels.)"""
+    from jova_amd import synth
+    from jova_amd._lib import P, call, stream
+    from jova_amd.nn import functional as F_
+    rng = np.random.RandomState(8)
+    mols = [synth.make_molecule(rng, int(n)) for n in rng.randint(8, 30, size=40)]
+    gl = _glist_dev(mols, device)
+    topo = F_.topology_of(gl)
+    n = gl[0].shape[0]
+    x = torch.randn(n, 64, device=device)
+    pooled, arg = torch.empty(n, 64, device=device), torch.empty(n, 64, dtype=torch.uint8, device=device)
+    a, b, bias = torch.randn(128, 1024, device=device), torch.randn(512, 1024, device=device), torch.randn(512, device=device)
+    c = torch.empty(128, 512, device=device)
+    ns_out, ns_df = torch.empty(n * 64, device=device), torch.empty(n * 64, device=device)
+    nev = torch.zeros(3, dtype=torch.int32, device=device)
+    stats = torch.empty(2, 64, dtype=torch.float64, device=device)
+
+    def run():
+        st = stream()
+        call("jova_colstats", P(x), n, 64, P(stats), st)
+        F_.gemm(F_._addr(a), 1024, 1, F_._addr(b), 1, 1024, F_._addr(c), 512, 128, 512, 1024, bias=P(bias))
+        call("jova_graphpool_fwd", P(x), n, 64, P(topo.deg_slice), topo.adj_ptrs, P(pooled), P(arg), None, st)
+        call("jova_nonsat_fwd_noalloc", P(pooled), n * 64, 1e-4, 100, P(ns_out), P(ns_df), P(nev), st)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()                                                    # warm-up outside the capture (lazy module loading)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run()
+    for trial in range(3):
+        x.copy_(torch.randn(n, 64, device=device) * (trial + 1))
+        a.copy_(torch.randn(128, 1024, device=device))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = (c.clone(), pooled.clone(), ns_out.clone(), stats.clone())
+        assert int(nev[2].item()) == 0 and not torch.isnan(got[2]).any()
+        run()
+        torch.cuda.synchronize()
+        assert torch.equal(got[1], pooled) and torch.equal(got[2], ns_out)
+        assert torch.allclose(got[3], stats, rtol=1e-12, atol=1e-9)
+        H.assert_close(got[0], c, tol=2e-6, what="captured gemm")   # (split-K partial sums: atomic order)
