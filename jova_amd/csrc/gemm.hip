@@ -594,8 +594,9 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
                      int64_t sA2, int64_t sB1, int64_t sB2, int64_t sC1, int64_t sC2, void* stream, float* csum,
                      bool* csum_done) {
     if (csum_done) *csum_done = false;
-    JOVA_CHECK_ARG(A && B && C, "gemm: null pointer");
     JOVA_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && nb1 >= 1 && nb2 >= 1, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    if (M == 0 || N == 0) return JOVA_OK;                    // (an empty product: pointers of empty tensors are null)
+    JOVA_CHECK_ARG(A && B && C, "gemm: null pointer");
     JOVA_CHECK_ARG(sam == 1 || sak == 1, "gemm: A needs a unit stride (sam=%lld sak=%lld)", (long long)sam, (long long)sak);
     JOVA_CHECK_ARG(sbk == 1 || sbn == 1, "gemm: B needs a unit stride (sbk=%lld sbn=%lld)", (long long)sbk, (long long)sbn);
     JOVA_CHECK_ARG(splitk >= 1 && (splitk == 1 || (!residual && !relu)), "gemm: split-K excludes residual/relu");

@@ -315,7 +315,8 @@ extern "C" int jova_optim_step(int kind, float* params, const float* grads, floa
                                int64_t n, float lr, float weight_decay, float grad_scale, int step, float h0, float h1,
                                float h2, void* stream) {
     JOVA_CHECK_ARG(kind >= 2 && kind <= 5, "optim_step: kind %d (2 adam, 3 rmsprop, 4 adagrad, 5 adadelta)", kind);
-    JOVA_CHECK_ARG(params && grads && state1 && n >= 0 && step >= 1, "optim_step: bad argument");
+    JOVA_CHECK_ARG(n >= 0 && step >= 1 && (n == 0 || (params && grads && state1)), "optim_step: bad argument");
+    if (n == 0) return JOVA_OK;
     JOVA_CHECK_ARG(state2_or_null || kind == 4 || (kind == 3 && h2 <= 0.f), "optim_step: this optimizer needs state2");
     if (n == 0) return JOVA_OK;
     float c0 = 1.f, c1 = 1.f;
@@ -340,7 +341,7 @@ __global__ void nonfinite_flag_kernel(const float* __restrict__ x, long long n, 
     if (bad) atomicOr(flag, 1);
 }
 extern "C" int jova_nonfinite_flag(const float* x, int64_t n, int* flag, void* stream) {
-    JOVA_CHECK_ARG(x && flag && n >= 0, "nonfinite_flag: bad argument");
+    JOVA_CHECK_ARG(flag && n >= 0 && (n == 0 || x), "nonfinite_flag: bad argument");
     if (n == 0) return JOVA_OK;
     hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, flag);
     JOVA_CHECK_LAUNCH("nonfinite_flag");
@@ -370,7 +371,7 @@ extern "C" int jova_adamax_step(float* params, const float* grads, float* exp_av
 }
 
 extern "C" int jova_relu_fwd(const float* x, int64_t n, float* y, void* stream) {
-    JOVA_CHECK_ARG(x && y && n >= 0, "relu_fwd: bad argument");
+    JOVA_CHECK_ARG(n >= 0 && (n == 0 || (x && y)), "relu_fwd: bad argument");
     if (n == 0) return JOVA_OK;
     hipLaunchKernelGGL(relu_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, y);
     JOVA_CHECK_LAUNCH("relu_fwd");
@@ -378,7 +379,7 @@ extern "C" int jova_relu_fwd(const float* x, int64_t n, float* y, void* stream) 
 }
 
 extern "C" int jova_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* stream) {
-    JOVA_CHECK_ARG(dy && y && dx && n >= 0, "relu_bwd: bad argument");
+    JOVA_CHECK_ARG(n >= 0 && (n == 0 || (dy && y && dx)), "relu_bwd: bad argument");
     if (n == 0) return JOVA_OK;
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, (long long)n, dx);
     JOVA_CHECK_LAUNCH("relu_bwd");

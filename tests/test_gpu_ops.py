@@ -995,3 +995,44 @@ def test_entry_points_capture_into_a_hip_graph(device):
         assert torch.equal(got[1], pooled) and torch.equal(got[2], ns_out)
         assert torch.allclose(got[3], stats, rtol=1e-12, atol=1e-9)
         H.assert_close(got[0], c, tol=2e-6, what="captured gemm")   # (split-K partial sums: atomic order)
+
+
+def test_new_entry_points_on_empty_and_ragged_inputs(device):
+    """Edge cases of the round-2 entry points: zero rows / zero steps are no-ops that return cleanly, out-of-range indices
+    of the row gather yield NaN rows and are skipped by the scatter, copy2d pads and crops."""
+    from jova_amd._lib import P, call, stream
+    from jova_amd.nn import functional as F_
+    st = stream()
+    e = torch.empty(0, 8, device=device)
+    idx0 = torch.empty(0, dtype=torch.int64, device=device)
+    assert F_.RowGatherFunction.apply(torch.randn(5, 8, device=device), idx0).shape == (0, 8)
+    out = F_.RowScatterAddFunction.apply(e, idx0, 4)
+    assert out.shape == (4, 8) and float(out.abs().max()) == 0.0
+    src = torch.arange(12, dtype=torch.float32, device=device).view(3, 4)
+    g = F_.RowGatherFunction.apply(src, torch.tensor([2, 0, 7, -1], device=device))
+    assert torch.equal(g[:2], src[[2, 0]]) and torch.isnan(g[2:]).all()
+    acc = torch.zeros(2, 4, device=device)
+    call("jova_scatter_add_rows", P(src), P(torch.tensor([1, 5, 1], device=device)), 3, 4, 2, P(acc), st)
+    assert torch.equal(acc[1], src[0] + src[2]) and float(acc[0].abs().max()) == 0.0
+    # copy2d: pad, crop, accumulate
+    dst = torch.full((4, 6), 9.0, device=device)
+    F_.copy2d(src, 3, 4, 4, dst, 4, 6, 6)
+    assert torch.equal(dst[:3, :4], src) and float(dst[3].abs().max()) == 0.0 and float(dst[:, 4:].abs().max()) == 0.0
+    crop = torch.ones(2, 3, device=device)
+    F_.copy2d(dst, 2, 3, 6, crop, 2, 3, 3, accumulate=True)
+    assert torch.equal(crop, src[:2, :3] + 1.0)
+    # LSTM: zero steps / zero batch
+    w_ih, w_hh = torch.randn(8, 5, device=device), torch.randn(8, 2, device=device)
+    b = torch.zeros(8, device=device)
+    assert F_.LstmFunction.apply(torch.empty(0, 3, 5, device=device), w_ih, w_hh, b, b, True).shape == (0, 3, 2)
+    assert F_.LstmFunction.apply(torch.empty(4, 0, 5, device=device), w_ih, w_hh, b, b, True).shape == (4, 0, 2)
+    # gaussian histogram rows sum to one; embedding of nothing
+    gh = F_.GaussHistFunction.apply(torch.randn(7, 3, device=device), 1e-7)
+    assert gh.shape == (7, 33) and torch.allclose(gh.view(7, 3, 11).sum(-1), torch.ones(7, 3, device=device), atol=1e-5)
+    assert F_.EmbeddingFunction.apply(torch.randn(4, 6, device=device), idx0).shape == (0, 6)
+    # optimizer step and non-finite flag on empty buffers
+    z = torch.empty(0, device=device)
+    call("jova_optim_step", 2, P(z), P(z), P(z), P(z), 0, 1e-3, 0.0, 1.0, 1, 0.9, 0.999, 1e-8, st)
+    flag = torch.zeros(1, dtype=torch.int32, device=device)
+    call("jova_nonfinite_flag", P(z), 0, P(flag), st)
+    assert int(flag.item()) == 0
