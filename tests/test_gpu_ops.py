@@ -66,10 +66,11 @@ def test_gemm_few_tiles_long_k_is_split_with_bias(device, shape):
     H.assert_close(C, want, tol=2e-6, what="few-tile split")
 
 
-@pytest.mark.parametrize("shape", [(3840, 2048, 512), (1280, 512, 512), (256, 128, 128), (640, 242, 242), (77, 22, 512)])
+@pytest.mark.parametrize("shape", [(3840, 2048, 512), (1280, 512, 512), (256, 128, 128), (640, 242, 242), (77, 22, 512),
+                                   (23168, 512, 22), (4099, 22, 242), (2048, 22, 22), (2500, 1, 300), (6000, 32, 512)])
 def test_linear_bwd_weight_fuses_the_bias_gradient(device, shape):
     """jova_linear_bwd_weight: dw += dy^T x and db += colsum(dy), both ACCUMULATING, on the aligned form (bias gradient
-    summed from the product's own A fragments, with and without split-K) and on the generic form (separate pass)."""
+    summed from the product's own A fragments, with and without split-K) and on the generic form (separate pass); one side <= 32 wide over >= 2048 rows takes the streaming reduction."""
     from jova_amd.nn import functional as F_
     rows, n_out, k_in = shape
     g = torch.Generator().manual_seed(rows + n_out)
@@ -80,7 +81,7 @@ def test_linear_bwd_weight_fuses_the_bias_gradient(device, shape):
     dyd, xd, dw, db = dy.to(device), x.to(device), dw0.to(device), db0.to(device)
     F_.linear_bwd_weight(dyd, xd, dw, db)
     H.assert_close(dw, want_dw, tol=2e-6, what="dw")
-    H.assert_close(db, want_db, tol=2e-6, what="db")
+    H.assert_close(db, want_db, tol=5e-6, what="db")             # fp32 sums of up to 23 k terms
     dw2 = dw0.to(device)
     F_.linear_bwd_weight(dyd, xd, dw2, None)                    # without a bias
     H.assert_close(dw2, want_dw, tol=2e-6, what="dw (no bias)")
