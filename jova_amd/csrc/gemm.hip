@@ -299,18 +299,24 @@ __device__ __forceinline__ int fswz(int row) { return FBK == 32 ? (row >> 1) & 7
 struct FastArgs {
     GemmArgs g;
     int ntm, ntn, items, nk_total, per, full, rem;
+    int tpb;        // ragged / batched form: tiles per matrix of the batch (tile / tpb = matrix index, nb2 fastest)
 };
 
 template <bool KC>
 struct OperandStream {                   // this lane's DMA source pointers into one operand + the k-tile step
     const float* p[FPCS];
     long long step;
-    __device__ __forceinline__ void set(const float* base, long long ld, int row0, int k0, int wave, int lane) {
+    // last_row >= 0 (ragged form, K-contiguous operands only): rows past the extent re-read the last row; their
+    // products are never stored
+    template <bool CLAMP = false>
+    __device__ __forceinline__ void set(const float* base, long long ld, int row0, int k0, int wave, int lane,
+                                        int last_row = 0) {
         if (KC) {
 #pragma unroll
             for (int pc = 0; pc < FPCS; ++pc) {
                 const int row = (wave * FPCS + pc) * FRP + lane / FCH;
-                p[pc] = base + (long long)(row0 + row) * ld + k0 + (((lane % FCH) ^ fswz(row)) << 2);
+                const int grow = CLAMP ? min(row0 + row, last_row) : row0 + row;
+                p[pc] = base + (long long)grow * ld + k0 + (((lane % FCH) ^ fswz(row)) << 2);
             }
             step = FBK;
         } else {
@@ -339,7 +345,10 @@ struct OperandStream {                   // this lane's DMA source pointers into
 __device__ unsigned long long gemm_probe[4 * 1024];     // dev-only: per workgroup: start, end (100 MHz), cycles, hw id
 #endif
 
-template <bool A_KC, bool B_KC>
+// RAG (both operands K-contiguous): a batch of matrices (nb2, strides s?1 / s?2 of GemmArgs) whose M and N need not be
+// multiples of 128 -- edge tiles read clamped rows and store guarded; used for the per-(b,h) attention products with
+// K = 256 (scores = Q K^T and dP = dO V^T), which otherwise run on the generic form at 0.6 of this one's rate.
+template <bool A_KC, bool B_KC, bool RAG = false>
 __global__ void __launch_bounds__(256, FWGS)
 gemm_f32_fast_kernel(FastArgs fa) {
 #ifdef GEMM_CLOCK_PROBE
@@ -365,8 +374,10 @@ gemm_f32_fast_kernel(FastArgs fa) {
     // work item -> tile origin and K range (in k-tiles)
     auto item_tile = [&](int it) { return it < fa.full ? it : fa.full + (it - fa.full) % fa.rem; };
     auto item_part = [&](int it) { return it < fa.full ? 0 : (it - fa.full) / fa.rem; };
-    auto item_m0 = [&](int it) { return (item_tile(it) / fa.ntn) * 128; };
-    auto item_n0 = [&](int it) { return (item_tile(it) % fa.ntn) * 128; };
+    auto item_mat = [&](int it) { return RAG ? item_tile(it) / fa.tpb : 0; };
+    auto item_loc = [&](int it) { return RAG ? item_tile(it) % fa.tpb : item_tile(it); };
+    auto item_m0 = [&](int it) { return (item_loc(it) / fa.ntn) * 128; };
+    auto item_n0 = [&](int it) { return (item_loc(it) % fa.ntn) * 128; };
     auto item_k0 = [&](int it) { return item_part(it) * fa.per; };
     auto item_nk = [&](int it) { return it < fa.full ? fa.nk_total : min(fa.per, fa.nk_total - item_part(it) * fa.per); };
 
@@ -382,8 +393,14 @@ gemm_f32_fast_kernel(FastArgs fa) {
         l_left = l_nk;
         l_wrap = item_rot(l_item);
         const int k0 = (item_k0(l_item) + l_wrap) * FBK;
-        sa.set(g.A, A_KC ? g.sam : g.sak, item_m0(l_item), k0, wave, lane);
-        sb.set(g.B, B_KC ? g.sbn : g.sbk, item_n0(l_item), k0, wave, lane);
+        if (RAG) {
+            const int z = item_mat(l_item), z1 = z / g.nb2, z2 = z - z1 * g.nb2;
+            sa.template set<true>(g.A + z1 * g.sA1 + z2 * g.sA2, g.sam, item_m0(l_item), k0, wave, lane, g.M - 1);
+            sb.template set<true>(g.B + z1 * g.sB1 + z2 * g.sB2, g.sbn, item_n0(l_item), k0, wave, lane, g.N - 1);
+        } else {
+            sa.set(g.A, A_KC ? g.sam : g.sak, item_m0(l_item), k0, wave, lane);
+            sb.set(g.B, B_KC ? g.sbn : g.sbk, item_n0(l_item), k0, wave, lane);
+        }
     };
     open_item();
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
@@ -490,11 +507,25 @@ gemm_f32_fast_kernel(FastArgs fa) {
         const int m0 = item_m0(it), n0 = item_n0(it);
         const bool first_split = item_part(it) == 0;
         const bool partial = it >= fa.full;
+        float* Cm = g.C;
+        if (RAG) {
+            const int z = item_mat(it), z1 = z / g.nb2, z2 = z - z1 * g.nb2;
+            Cm += z1 * g.sC1 + z2 * g.sC2;
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const int n = n0 + wn + 32 * b + i;
+                if (RAG) {                                   // guarded plain stores (alpha, optional bias; nothing else)
+                    const float bias = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wm + 32 * a + mfma32_row(r, lane);
+                        if (m < g.M && n < g.N) Cm[(long long)m * g.ldc + n] = g.alpha * acc[a][b][r] + bias;
+                    }
+                    continue;
+                }
                 const float bias = (g.bias && first_split) ? g.bias[n] : 0.f;
                 float* crow = g.C + n;
                 if (partial) {
@@ -631,6 +662,36 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
                 (long long)a_ld, (long long)b_ld, (long long)ldc);
     const bool fast = fast_env && nb1 == 1 && nb2 == 1 && M % 128 == 0 && N % 128 == 0 && K % FBK == 0 && K > 0 && va &&
                       vb && aligned16(C) && (!residual || true);
+    // ragged / batched aligned form: both operands K-contiguous, no residual / ReLU / split (S <= 256 of the attention
+    // products; S = 279 would pad to 384 and stays on the 96-tiles of the generic form)
+    static int rag_env = -1;
+    if (rag_env < 0) rag_env = getenv("JOVA_GEMM_NO_RAGGED") ? 0 : 1;
+    if (!fast && fast_env && rag_env && a_kc && b_kc && K % FBK == 0 && K > 0 && va && vb && !residual && !relu && splitk == 1 &&
+        (nb1 > 1 || nb2 > 1)) {
+        const long long tm = cdiv(M, 128), tn = cdiv(N, 128), nbt = (long long)nb1 * nb2;
+        // padded work against the generic form's best tile size (same weights as its own choice below), this form
+        // running at about 1.5 x the generic 128-tile rate
+        double generic = 1e300;
+        for (int w = 4; w >= 2; --w) {
+            const double c = (double)cdiv(M, 32 * w) * cdiv(N, 32 * w) * (32 * w) * (32 * w) * (w == 4 ? 1.0 : (w == 3 ? 1.2 : 1.25));
+            if (c < generic) generic = c;
+        }
+        if ((double)tm * tn * 128 * 128 <= 1.5 * generic && tm * tn * nbt >= 256 && tm * tn * nbt < (1ll << 30)) {
+            FastArgs fa;
+            fa.g = g;
+            fa.ntm = (int)tm;
+            fa.ntn = (int)tn;
+            fa.tpb = (int)(tm * tn);
+            fa.nk_total = K / FBK;
+            fa.full = fa.items = (int)(tm * tn * nbt);
+            fa.rem = 0;
+            fa.per = fa.nk_total;
+            const int slots = 256 * FWGS, nwg = fa.items < slots ? fa.items : slots;
+            hipLaunchKernelGGL((gemm_f32_fast_kernel<true, true, true>), dim3(nwg), dim3(256), 0, s, fa);
+            JOVA_CHECK_LAUNCH("gemm_f32_fast (ragged)");
+            return JOVA_OK;
+        }
+    }
     if (fast) {
         if (csum && !a_kc) {
             g.csum = csum;
@@ -638,6 +699,7 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
         }
         FastArgs fa;
         fa.g = g;
+        fa.tpb = 0;
         fa.ntm = M / 128;
         fa.ntn = N / 128;
         fa.nk_total = K / FBK;

@@ -87,6 +87,28 @@ def test_linear_bwd_weight_fuses_the_bias_gradient(device, shape):
     H.assert_close(dw2, want_dw, tol=2e-6, what="dw (no bias)")
 
 
+@pytest.mark.parametrize("shape", [(241, 241, 256, 32, 2), (256, 203, 64, 64, 1), (130, 250, 16, 3, 40)])
+def test_gemm_ragged_batched_aligned_form(device, shape):
+    """The per-(b,h) attention products with K = head_dim (scores = Q K^T, dP = dO V^T) take the aligned kernel although S
+    is no multiple of 128: edge tiles read clamped rows and store guarded.  Operands laid out like qkv ([S, B, 3L])
+    with NaN everywhere the product must not read or write."""
+    from jova_amd.nn import functional as F_
+    S1, S2, hd, nb1, nb2 = shape
+    g = torch.Generator().manual_seed(S1 + S2)
+    L = nb2 * hd
+    q = torch.randn(S1, nb1, L, generator=g)
+    k = torch.randn(S2, nb1, L, generator=g)
+    want = torch.einsum("sbhd,tbhd->bhst", q.view(S1, nb1, nb2, hd).double(), k.view(S2, nb1, nb2, hd).double()) * 0.125
+    Sp = (S2 + 3) // 4 * 4
+    qd, kd = q.to(device), k.to(device)
+    C = torch.full((nb1 * nb2, S1, Sp), float("nan"), device=device)
+    F_.gemm(F_._addr(qd), nb1 * L, 1, F_._addr(kd), 1, nb1 * L, F_._addr(C), Sp, S1, S2, hd, alpha=0.125, nb1=nb1, nb2=nb2,
+            sA=(L, hd), sB=(L, hd), sC=(nb2 * S1 * Sp, S1 * Sp))
+    got = C.view(nb1, nb2, S1, Sp)
+    H.assert_close(got[..., :S2], want.float(), tol=2e-6, what="ragged batched product")
+    assert torch.isnan(got[..., S2:]).all(), "wrote into the row padding"
+
+
 @pytest.mark.parametrize("layout", ["kc", "rc"])
 def test_gemm_padded_rows_with_garbage_in_the_padding(device, layout):
     """Operands whose rows are padded to a multiple of 4 floats (the attention probabilities [S, S4]) take the 16-byte
