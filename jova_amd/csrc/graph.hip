@@ -1682,9 +1682,13 @@ gather2d_bwd_v4_kernel(const float* __restrict__ dout, const int* __restrict__ m
 // ctrl[0] = evaluations done, ctrl[1] = arrival counter, ctrl[2] = timeout flag.
 #define NS_MAX_BLOCKS 512
 #define NS_THREADS 1024
+#define NS_RESIDENT 4
 // VEC = 4: every access is 16 bytes (n % 4 == 0, 16-byte aligned buffers); element order inside the sums differs from
 // VEC = 1 only in which lane adds which element - the per-workgroup partials are fp64 and combined in a fixed order.
-template <int VEC>
+// RES > 0 (VEC = 4): every thread owns at most RES 16-byte pieces, which then stay in registers from the first evaluation
+// to the last (x, the iterate and its predecessor): nothing but the barrier words moves between evaluations.  Same
+// elements per thread, same order of the sums as the memory form, so the results are the same bits.
+template <int VEC, int RES>
 __global__ void __launch_bounds__(NS_THREADS)
 nonsat_persistent_kernel(const float* __restrict__ x, float* __restrict__ ya, float* __restrict__ yb, long long n,
                          float ep, int max_iter, double* partial, int* ctrl, float* __restrict__ out,
@@ -1697,11 +1701,37 @@ nonsat_persistent_kernel(const float* __restrict__ x, float* __restrict__ ya, fl
     const long long e0 = ((long long)blockIdx.x * NS_THREADS + tid) * VEC;
     int evals = 0;
     bool failed = false;
+    constexpr int NR = RES > 0 ? RES : 1;
+    float xr[NR][VEC], yc[NR][VEC], yv[NR][VEC];          // resident form: x, current iterate, its predecessor
+    if (RES > 0) {
+#pragma unroll
+        for (int sl = 0; sl < NR; ++sl) {
+            const long long e = e0 + sl * stride;
+            if (e < n) *reinterpret_cast<float4*>(xr[sl]) = *reinterpret_cast<const float4*>(x + e);
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) yc[sl][u] = yv[sl][u] = xr[sl][u];
+        }
+    }
     for (int it = 0;; ++it) {
         const float* yin = (it & 1) ? yb : ya;
         float* yout = (it & 1) ? ya : yb;
         double acc = 0.0;
-        for (long long e = e0; e < n; e += stride) {
+        if (RES > 0) {
+#pragma unroll
+            for (int sl = 0; sl < NR; ++sl) {
+                if (e0 + sl * stride < n) {
+#pragma unroll
+                    for (int u = 0; u < VEC; ++u) {
+                        const float y = yc[sl][u];
+                        const float yn = (2.f * (y * y * y) / 3.f + xr[sl][u]) / (y * y + 1.f);
+                        acc += (double)fabsf(yn - y);
+                        yv[sl][u] = y;
+                        yc[sl][u] = yn;
+                    }
+                }
+            }
+        }
+        for (long long e = e0; RES == 0 && e < n; e += stride) {
             float xv[VEC], y[VEC], yn[VEC];
             if (VEC == 4) {
                 *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + e);
@@ -1778,6 +1808,20 @@ nonsat_persistent_kernel(const float* __restrict__ x, float* __restrict__ ya, fl
         const float qnan = __builtin_nanf("");
         for (long long e = e0; e < n; e += stride)
             for (int u = 0; u < VEC; ++u) { out[e + u] = qnan; dfac[e + u] = qnan; }
+        return;
+    }
+    if (RES > 0) {
+#pragma unroll
+        for (int sl = 0; sl < NR; ++sl) {
+            const long long e = e0 + sl * stride;
+            if (e < n) {
+                *reinterpret_cast<float4*>(out + e) = *reinterpret_cast<const float4*>(yc[sl]);
+                *reinterpret_cast<float4*>(dfac + e) =
+                    make_float4(1.f / (yv[sl][0] * yv[sl][0] + 1.f), 1.f / (yv[sl][1] * yv[sl][1] + 1.f),
+                                1.f / (yv[sl][VEC > 1 ? 2 : 0] * yv[sl][VEC > 1 ? 2 : 0] + 1.f),
+                                1.f / (yv[sl][VEC > 1 ? 3 : 0] * yv[sl][VEC > 1 ? 3 : 0] + 1.f));
+            }
+        }
         return;
     }
     // evaluation evals-1 wrote (evals-1 even ? yb : ya); its input y_prev is x (evals == 1) or the other buffer
@@ -3752,7 +3796,8 @@ static int nonsat_block_cap(int* cap) {
     static int cached = 0;
     if (cached == 0) {
         int per_cu = 0;
-        JOVA_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nonsat_persistent_kernel<VEC>, NS_THREADS, 0));
+        JOVA_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nonsat_persistent_kernel<VEC, (VEC == 4 ? NS_RESIDENT : 0)>,
+                                                                     NS_THREADS, 0));
         if (per_cu < 1) {
             jova_set_error("nonsat_fwd: the persistent kernel does not fit a CU (occupancy query returned %d)", per_cu);
             return JOVA_ERR_LIMIT;
@@ -3792,11 +3837,17 @@ static int nonsat_launch(const float* x, int64_t n, float ep, int max_iter, floa
     const int rc = vec4 ? nonsat_block_cap<4>(&cap) : nonsat_block_cap<1>(&cap);
     if (rc != JOVA_OK) return rc;
     if (blocks > cap) blocks = cap;
-    if (vec4)
-        hipLaunchKernelGGL(nonsat_persistent_kernel<4>, dim3(blocks), dim3(NS_THREADS), 0, s, x, ya, yb, (long long)n, ep,
+    // up to NS_RESIDENT 16-byte pieces per thread: the iterates never leave the registers (the Davis batch: 1 M elements)
+    static int res_env = -1;
+    if (res_env < 0) res_env = getenv("JOVA_NONSAT_NO_RESIDENT") ? 0 : 1;
+    if (vec4 && res_env && n <= (long long)blocks * per_block * NS_RESIDENT)
+        hipLaunchKernelGGL((nonsat_persistent_kernel<4, NS_RESIDENT>), dim3(blocks), dim3(NS_THREADS), 0, s, x, ya, yb,
+                           (long long)n, ep, max_iter, partial, ctrl, out, dfac, n_eval_dev, g_ns_spin_limit);
+    else if (vec4)
+        hipLaunchKernelGGL((nonsat_persistent_kernel<4, 0>), dim3(blocks), dim3(NS_THREADS), 0, s, x, ya, yb, (long long)n, ep,
                            max_iter, partial, ctrl, out, dfac, n_eval_dev, g_ns_spin_limit);
     else
-        hipLaunchKernelGGL(nonsat_persistent_kernel<1>, dim3(blocks), dim3(NS_THREADS), 0, s, x, ya, yb, (long long)n, ep,
+        hipLaunchKernelGGL((nonsat_persistent_kernel<1, 0>), dim3(blocks), dim3(NS_THREADS), 0, s, x, ya, yb, (long long)n, ep,
                            max_iter, partial, ctrl, out, dfac, n_eval_dev, g_ns_spin_limit);
     JOVA_CHECK_LAUNCH("nonsat_persistent");
     return JOVA_OK;
