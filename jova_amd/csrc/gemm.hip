@@ -670,13 +670,15 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
         (nb1 > 1 || nb2 > 1)) {
         const long long tm = cdiv(M, 128), tn = cdiv(N, 128), nbt = (long long)nb1 * nb2;
         // padded work against the generic form's best tile size (same weights as its own choice below), this form
-        // running at about 1.5 x the generic 128-tile rate
+        // running at about 1.15 x the generic 128-tile rate (measured at S = 241: 105 against 122 us).  Only up to 2 x 2
+        // tiles per matrix: at S = 400-1100 (Metz + PSC, long-protein batches) the generic form measured 1-2 % better on
+        // the step -- with K = 256 an item is 16 k-tiles long and this kernel's per-item costs weigh more than its rate
         double generic = 1e300;
         for (int w = 4; w >= 2; --w) {
             const double c = (double)cdiv(M, 32 * w) * cdiv(N, 32 * w) * (32 * w) * (32 * w) * (w == 4 ? 1.0 : (w == 3 ? 1.2 : 1.25));
             if (c < generic) generic = c;
         }
-        if ((double)tm * tn * 128 * 128 <= 1.5 * generic && tm * tn * nbt >= 256 && tm * tn * nbt < (1ll << 30)) {
+        if (tm <= 2 && tn <= 2 && (double)tm * tn * 128 * 128 <= 1.15 * generic && tm * tn * nbt >= 256 && tm * tn * nbt < (1ll << 30)) {
             FastArgs fa;
             fa.g = g;
             fa.ntm = (int)tm;
