@@ -616,6 +616,190 @@ gemm_f32_fast_kernel(FastArgs fa) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ fp32 from bf16 pieces
+// C = alpha A B (+ bias, residual, ReLU / ReLU mask; split-K parts add with float atomics), fp32 in, fp32 out, at fp32
+// accuracy on the bf16 matrix pipe (16 x the fp32 MFMA rate).  Every operand element is split on the fly into three
+// bf16 pieces x = h + m + l (round-to-nearest at each level; the residual of a level is exact in fp32, so |x - (h+m+l)|
+// <= 2^-24 |x|) and a product keeps the six piece products of weight >= 2^-16: hh, hm, mh, mm, hl, lh -- each exact in
+// the fp32 accumulator of v_mfma_f32_32x32x16_bf16 -- and drops ml, lm, ll (<= 2^-23 of the product, the size of the
+// rounding of one fp32 FMA).  Measured against fp64 on the FFN shapes it is as close as an fp32 FMA chain
+// (tools/scratch/gemm_bf16x3_lab.hip: K = 512: 5.9e-7 against 8.2e-7 of max|C|; K = 2048: 2.0e-6 against 1.5e-6).
+// Used for the BACKWARD products only (dX = dY W and dW = dY^T X: B row-contiguous): the forward products stay on the fp32
+// MFMA kernels, so every forward value -- and with it every ReLU mask -- is what it was.
+// 128 x 128 output tile, 4 waves of 64 x 64, k-tiles of 32: global (fp32) -> registers -> split -> LDS ([piece][row][k],
+// 80-byte rows: the 16-byte fragment reads of 16 lanes cover all banks once) while the MFMAs of the previous k-tile run;
+// a row-contiguous operand is read as 4 x 4 blocks per thread and transposed in registers on its way to LDS.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+constexpr int XBK = 32, XLD = 40;
+
+struct X3Args {
+    GemmArgs g;
+    int ntm, ntn, nk_total, per, parts;          // k-tiles in all, per split part; parts > 1: C accumulates (atomics)
+};
+
+__device__ __forceinline__ float bf16_up(__bf16 v) {
+    return __uint_as_float(((unsigned)(*reinterpret_cast<unsigned short*>(&v))) << 16);
+}
+__device__ __forceinline__ void split4(const float v[4], bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 hi = (__bf16)v[i];
+        const float r1 = v[i] - bf16_up(hi);
+        const __bf16 mi = (__bf16)r1;
+        h[i] = hi;
+        m[i] = mi;
+        l[i] = (__bf16)(r1 - bf16_up(mi));
+    }
+}
+
+// 8-byte k-chunk c of row r sits at chunk c ^ x3_swz(r) (even values: a fragment's 16-byte chunk pair stays together and
+// in order): the transposing store of a row-contiguous operand (32 lanes on rows 4 apart, 320 bytes) would otherwise hit
+// the same banks 8 times over
+__device__ __forceinline__ int x3_swz(int row) { return ((row >> 4) & 3) << 1; }
+
+template <bool KC>
+struct X3Operand {                      // one 128 x 32 operand tile: global -> registers -> three bf16 images in LDS
+    float r[4][4];
+    __device__ __forceinline__ void load(const float* base, long long ld, int row0, int k0, int tid) {
+        if (KC) {                       // element (row, k) at row * ld + k: 4 x (16 bytes of one row)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = tid + 256 * j, row = f >> 3, c4 = f & 7;
+                *reinterpret_cast<float4*>(r[j]) = *reinterpret_cast<const float4*>(base + (long long)(row0 + row) * ld + k0 + c4 * 4);
+            }
+        } else {                        // element (row, k) at k * ld + row: a 4 (k) x 4 (rows) block
+            const int nb = tid & 31, kb = tid >> 5;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                *reinterpret_cast<float4*>(r[kk]) =
+                    *reinterpret_cast<const float4*>(base + (long long)(k0 + 4 * kb + kk) * ld + row0 + 4 * nb);
+        }
+    }
+    __device__ __forceinline__ void store(__bf16 (*s)[128][XLD], int tid) const {
+        if (KC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = tid + 256 * j, row = f >> 3, c4 = f & 7;
+                bf16x4 p0, p1, p2;
+                split4(r[j], p0, p1, p2);
+                const int c = (c4 ^ x3_swz(row)) * 4;
+                *reinterpret_cast<bf16x4*>(&s[0][row][c]) = p0;
+                *reinterpret_cast<bf16x4*>(&s[1][row][c]) = p1;
+                *reinterpret_cast<bf16x4*>(&s[2][row][c]) = p2;
+            }
+        } else {
+            const int nb = tid & 31, kb = tid >> 5;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v[4] = {r[0][j], r[1][j], r[2][j], r[3][j]};
+                bf16x4 p0, p1, p2;
+                split4(v, p0, p1, p2);
+                const int c = (kb ^ x3_swz(4 * nb + j)) * 4;
+                *reinterpret_cast<bf16x4*>(&s[0][4 * nb + j][c]) = p0;
+                *reinterpret_cast<bf16x4*>(&s[1][4 * nb + j][c]) = p1;
+                *reinterpret_cast<bf16x4*>(&s[2][4 * nb + j][c]) = p2;
+            }
+        }
+    }
+};
+
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(256, 2)
+gemm_bf16x3_kernel(X3Args xa) {
+    __shared__ __attribute__((aligned(16))) __bf16 sA[3][128][XLD];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[3][128][XLD];
+    __shared__ float s_cs[128];
+    const GemmArgs& g = xa.g;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int tiles = xa.ntm * xa.ntn;
+    const int tile = blockIdx.x % tiles, part = blockIdx.x / tiles;
+    const int m0 = (tile / xa.ntn) * 128, n0 = (tile % xa.ntn) * 128;
+    const int kt0 = part * xa.per, nk = min(xa.per, xa.nk_total - kt0);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const bool do_cs = !A_KC && g.csum != nullptr && n0 == 0;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 128) s_cs[tid] = 0.f;
+    X3Operand<A_KC> oa;
+    X3Operand<B_KC> ob;
+    const long long lda = A_KC ? g.sam : g.sak, ldb = B_KC ? g.sbn : g.sbk;
+    oa.load(g.A, lda, m0, kt0 * XBK, tid);
+    ob.load(g.B, ldb, n0, kt0 * XBK, tid);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                         // every wave is past its fragment reads of the previous k-tile
+        if (do_cs) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cs[j] += (oa.r[0][j] + oa.r[1][j]) + (oa.r[2][j] + oa.r[3][j]);
+        }
+        oa.store(sA, tid);
+        ob.store(sB, tid);
+        __syncthreads();
+        if (kt + 1 < nk) {                       // the next k-tile travels while this one is multiplied
+            oa.load(g.A, lda, m0, (kt0 + kt + 1) * XBK, tid);
+            ob.load(g.B, ldb, n0, (kt0 + kt + 1) * XBK, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[3][2], fb[3][2];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fa[p][t] = *reinterpret_cast<const bf16x8*>(&sA[p][wm + 32 * t + i][((ks * 4 + 2 * h) ^ x3_swz(wm + 32 * t + i)) * 4]);
+                    fb[p][t] = *reinterpret_cast<const bf16x8*>(&sB[p][wn + 32 * t + i][((ks * 4 + 2 * h) ^ x3_swz(wn + 32 * t + i)) * 4]);
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {    // small terms first
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][a], fb[2][b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][a], fb[0][b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][a], fb[1][b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][a], fb[1][b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][a], fb[0][b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][a], fb[0][b], acc[a][b], 0, 0, 0);
+                }
+        }
+    }
+    const bool first = part == 0, partial = g.splitk > 1;       // split-K by contract ADDS onto C, even as a single part
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = n0 + wn + 32 * b + i;
+            const float bias = (g.bias && first) ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * a + mfma32_row(r, lane);
+                float v = g.alpha * acc[a][b][r] + bias;
+                if (partial) {
+                    if (g.R && first) v += g.R[(long long)m * g.ldr + n];
+                    atomicAdd(&g.C[(long long)m * g.ldc + n], v);
+                } else {
+                    const float rv = g.R ? g.R[(long long)m * g.ldr + n] : 0.f;
+                    if (g.relu == 2) v = rv > 0.f ? v : 0.f;
+                    else v += rv;
+                    if (g.relu == 1) v = fmaxf(v, 0.f);
+                    g.C[(long long)m * g.ldc + n] = v;
+                }
+            }
+        }
+    if (do_cs) {                                 // (A row-contiguous: thread (nb, kb) carried rows 4 nb .. 4 nb + 3)
+        const int nb = tid & 31;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(&s_cs[4 * nb + j], cs[j]);
+        __syncthreads();
+        if (tid < 128) atomicAdd(&g.csum[m0 + tid], s_cs[tid]);
+    }
+}
+
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // csum / csum_done: the column sums of A, if the form that runs can add them up on the way (aligned form, A row-contiguous)
@@ -660,6 +844,36 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
         fprintf(stderr, "gemm M=%d N=%d K=%d a_kc=%d b_kc=%d va=%d vb=%d nb=%dx%d splitk=%d relu=%d res=%d lda=%lld ldb=%lld ldc=%lld\n",
                 M, N, K, (int)a_kc, (int)b_kc, (int)va, (int)vb, nb1, nb2, splitk, relu, residual != nullptr,
                 (long long)a_ld, (long long)b_ld, (long long)ldc);
+    // backward products (B row-contiguous: dX = dY W, dW = dY^T X) of at least a GFLOP on aligned shapes: fp32 from three
+    // bf16 pieces on the bf16 matrix pipe (gemm_bf16x3_kernel).  One launch each, kernel trace, fp32 MFMA kernel -> this one:
+    // dX / dW of 30 848 x 2048 x 512: 568 / 533 -> 446 / 417 us; x 512 x 2048: 591 / 527 -> 468 / 406; x 1536 x 512: 424 / 416
+    // -> 332 / 324; x 512 x 512: 151 / 153 -> 128 / 123; 23 168 x 256 x 256: 43 / 46 -> 41 / 40 (tools/x3_shapes.py).
+    // JOVA_GEMM_NO_BF16X3 keeps everything on the fp32 MFMA kernel.
+    static int x3_env = -1, x3_all = 0;
+    if (x3_env < 0) {
+        x3_env = getenv("JOVA_GEMM_NO_BF16X3") ? 0 : 1;
+        x3_all = getenv("JOVA_GEMM_BF16X3_ALL") ? 1 : 0;              // (measurements: every aligned backward shape)
+    }
+    if (x3_env && fast_env && nb1 == 1 && nb2 == 1 && !b_kc && M % 128 == 0 && N % 128 == 0 && K % XBK == 0 && K > 0 && va && vb &&
+        (x3_all || (long long)M * N * K >= (1ll << 30)) && (splitk == 1 || ldc == N)) {
+        X3Args xa;
+        xa.g = g;
+        xa.ntm = M / 128;
+        xa.ntn = N / 128;
+        xa.nk_total = K / XBK;
+        xa.per = (xa.nk_total + splitk - 1) / splitk;
+        xa.parts = (xa.nk_total + xa.per - 1) / xa.per;
+        if (csum && !a_kc) {
+            xa.g.csum = csum;
+            if (csum_done) *csum_done = true;
+        }
+        const long long nwg = (long long)xa.ntm * xa.ntn * xa.parts;
+        JOVA_CHECK_ARG(nwg < (1ll << 31), "gemm: too many tiles");
+        if (a_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), dim3((unsigned)nwg), dim3(256), 0, s, xa);
+        else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), dim3((unsigned)nwg), dim3(256), 0, s, xa);
+        JOVA_CHECK_LAUNCH("gemm_bf16x3");
+        return JOVA_OK;
+    }
     const bool fast = fast_env && nb1 == 1 && nb2 == 1 && M % 128 == 0 && N % 128 == 0 && K % FBK == 0 && K > 0 && va &&
                       vb && aligned16(C) && (!residual || true);
     // ragged / batched aligned form: both operands K-contiguous, no residual / ReLU / split (S <= 256 of the attention

@@ -1,0 +1,200 @@
+// Lab harness (not part of the library): C[M,N] = A[M,K] B[N,K]^T in fp32 ACCURACY from bf16 matrix instructions.
+// Every fp32 operand is split on the fly into three bf16 pieces x = h + m + l (round-to-nearest at each level, the
+// residual of each level is exact in fp32); a product keeps the six piece products of weight >= 2^-16
+// (hh, hm, mh, mm, hl, lh; each is exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16) and drops ml, lm, ll
+// (<= 2^-23 of the product).  Question: how much of the 16 x rate of the bf16 pipe survives the 6 x instruction count, the
+// split arithmetic and 1.5 x the LDS bytes -- against 126 TFLOP/s of the fp32 kernel on the FFN shape.
+//   hipcc -O3 --offload-arch=gfx950 -o gemm_bf16x3_lab gemm_bf16x3_lab.hip && ./gemm_bf16x3_lab [M N K]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+constexpr int BM = 128, BN = 128, BK = 32, LDR = 40;       // LDR: bf16 per LDS row (80 bytes: 16-lane groups of 16-byte reads are conflict-free)
+
+__device__ __forceinline__ float bf16_up(__bf16 v) {
+    return __uint_as_float(((unsigned)(*reinterpret_cast<unsigned short*>(&v))) << 16);
+}
+
+// x[4] -> three bf16x4 pieces
+__device__ __forceinline__ void split4(const float4 x, bf16x4& h, bf16x4& m, bf16x4& l) {
+    const float v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 hi = (__bf16)v[i];
+        const float r1 = v[i] - bf16_up(hi);
+        const __bf16 mi = (__bf16)r1;
+        const float r2 = r1 - bf16_up(mi);
+        h[i] = hi;
+        m[i] = mi;
+        l[i] = (__bf16)r2;
+    }
+}
+
+template <int NTERMS>                  // 6: hh hm mh mm hl lh; 3: hh hm mh (bf16x2-like accuracy, for comparison)
+__global__ void __launch_bounds__(256, 2)
+gemm_bf16x3_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) __bf16 sA[3][BM][LDR];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[3][BN][LDR];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int ntn = N / BN;
+    const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + 256 * j, row = f >> 3, c4 = f & 7;
+            ra[j] = *reinterpret_cast<const float4*>(A + (long long)(m0 + row) * K + k0 + c4 * 4);
+            rb[j] = *reinterpret_cast<const float4*>(B + (long long)(n0 + row) * K + k0 + c4 * 4);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + 256 * j, row = f >> 3, c4 = f & 7;
+            bf16x4 p0, p1, p2;
+            split4(ra[j], p0, p1, p2);
+            *reinterpret_cast<bf16x4*>(&sA[0][row][c4 * 4]) = p0;
+            *reinterpret_cast<bf16x4*>(&sA[1][row][c4 * 4]) = p1;
+            *reinterpret_cast<bf16x4*>(&sA[2][row][c4 * 4]) = p2;
+            split4(rb[j], p0, p1, p2);
+            *reinterpret_cast<bf16x4*>(&sB[0][row][c4 * 4]) = p0;
+            *reinterpret_cast<bf16x4*>(&sB[1][row][c4 * 4]) = p1;
+            *reinterpret_cast<bf16x4*>(&sB[2][row][c4 * 4]) = p2;
+        }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (k0 + BK < K) gload(k0 + BK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[3][2], fb[3][2];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fa[p][t] = *reinterpret_cast<const bf16x8*>(&sA[p][wm + 32 * t + i][ks * 16 + 8 * h]);
+                    fb[p][t] = *reinterpret_cast<const bf16x8*>(&sB[p][wn + 32 * t + i][ks * 16 + 8 * h]);
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if (NTERMS == 6) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][a], fb[2][b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][a], fb[0][b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][a], fb[1][b], acc[a][b], 0, 0, 0);
+                    }
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][a], fb[1][b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][a], fb[0][b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][a], fb[0][b], acc[a][b], 0, 0, 0);
+                }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                C[(long long)m * N + n0 + wn + 32 * b + i] = acc[a][b][r];
+            }
+}
+
+// plain fp32 FMA reference on the device for a sample of rows (one thread per output), summed in k order
+__global__ void ref_rows_kernel(const float* A, const float* B, float* Cr, double* Cd, int N, int K, const int* rows, int nrows) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)nrows * N) return;
+    const int r = rows[e / N], n = (int)(e % N);
+    float s = 0.f;
+    double d = 0.0;
+    for (int k = 0; k < K; ++k) {
+        s = fmaf(A[(long long)r * K + k], B[(long long)n * K + k], s);
+        d += (double)A[(long long)r * K + k] * (double)B[(long long)n * K + k];
+    }
+    Cr[e] = s;
+    Cd[e] = d;
+}
+
+int main(int argc, char** argv) {
+    int M = 35712, N = 2048, K = 512;
+    if (argc >= 4) { M = atoi(argv[1]); N = atoi(argv[2]); K = atoi(argv[3]); }
+    if (M % BM || N % BN || K % BK) { printf("M %% 128, N %% 128, K %% 32 must be 0\n"); return 1; }
+    std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+    unsigned long long st = 88172645463325252ull;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (float)((st >> 11) * (1.0 / 9007199254740992.0)); };
+    for (auto& v : hA) { const float u = rnd(), w = rnd(); v = sqrtf(-2.f * logf(u + 1e-12f)) * cosf(6.2831853f * w); }   // N(0,1)
+    for (auto& v : hB) { const float u = rnd(), w = rnd(); v = 0.05f * sqrtf(-2.f * logf(u + 1e-12f)) * cosf(6.2831853f * w); }
+    float *dA, *dB, *dC, *dCr;
+    double* dCd;
+    int* dRows;
+    const int nrows = 64;
+    std::vector<int> rows(nrows);
+    for (int r = 0; r < nrows; ++r) rows[r] = (int)((long long)r * (M - 1) / (nrows - 1));
+    CHECK(hipMalloc(&dA, sizeof(float) * hA.size()));
+    CHECK(hipMalloc(&dB, sizeof(float) * hB.size()));
+    CHECK(hipMalloc(&dC, sizeof(float) * (size_t)M * N));
+    CHECK(hipMalloc(&dCr, sizeof(float) * (size_t)nrows * N));
+    CHECK(hipMalloc(&dCd, sizeof(double) * (size_t)nrows * N));
+    CHECK(hipMalloc(&dRows, sizeof(int) * nrows));
+    CHECK(hipMemcpy(dA, hA.data(), sizeof(float) * hA.size(), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(dB, hB.data(), sizeof(float) * hB.size(), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(dRows, rows.data(), sizeof(int) * nrows, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(ref_rows_kernel, dim3((nrows * N + 255) / 256), dim3(256), 0, 0, dA, dB, dCr, dCd, N, K, dRows, nrows);
+    CHECK(hipDeviceSynchronize());
+    std::vector<float> hCr((size_t)nrows * N), hC((size_t)nrows * N);
+    std::vector<double> hCd((size_t)nrows * N);
+    CHECK(hipMemcpy(hCr.data(), dCr, sizeof(float) * hCr.size(), hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(hCd.data(), dCd, sizeof(double) * hCd.size(), hipMemcpyDeviceToHost));
+    double scale = 0.0, e32 = 0.0;
+    for (size_t e = 0; e < hCd.size(); ++e) { scale = fmax(scale, fabs(hCd[e])); e32 = fmax(e32, fabs((double)hCr[e] - hCd[e])); }
+    printf("M %d N %d K %d   fp32 FMA chain vs fp64: max err / max|C| = %.3e\n", M, N, K, e32 / scale);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    const dim3 grid((M / BM) * (N / BN));
+    for (int variant = 0; variant < 2; ++variant) {
+        auto launch = [&]() {
+            if (variant == 0) hipLaunchKernelGGL(gemm_bf16x3_kernel<6>, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
+            else hipLaunchKernelGGL(gemm_bf16x3_kernel<3>, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
+        };
+        for (int w = 0; w < 20; ++w) launch();
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0, 0));
+        const int reps = 20;
+        for (int w = 0; w < reps; ++w) launch();
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipDeviceSynchronize());
+        float ms = 0.f;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / reps;
+        double err = 0.0;
+        for (int r = 0; r < nrows; ++r) {
+            CHECK(hipMemcpy(hC.data() + (size_t)r * N, dC + (size_t)rows[r] * N, sizeof(float) * N, hipMemcpyDeviceToHost));
+        }
+        for (size_t e = 0; e < hCd.size(); ++e) err = fmax(err, fabs((double)hC[e] - hCd[e]));
+        printf("%d piece products: %8.1f us  %7.1f TFLOP/s (fp32-equivalent)   vs fp64: max err / max|C| = %.3e\n",
+               variant == 0 ? 6 : 3, us, 2.0 * M * N * K / us * 1e-6, err / scale);
+    }
+    return 0;
+}
