@@ -407,6 +407,27 @@ def main():
     if not np.isfinite(final_loss):
         raise SystemExit("non-finite loss")
     trainer.check_health()
+    # the same K steps with the backward products kept on the fp32 MFMA kernel (jova_gemm_set_bf16x3(0)): what the
+    # bf16-pieces backward GEMM is worth, and the number to take if that form is not accepted as fp32 arithmetic
+    from jova_amd._lib import lib as _jova_lib
+    _jova_lib().jova_gemm_set_bf16x3(0)
+    for i in range(min(args.warmup, 2)):
+        trainer.step(batches[i % len(batches)])
+    sync_all()
+    t3 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.step(batches[i % len(batches)])
+    sync_all()
+    elapsed_f = time.perf_counter() - t3
+    _jova_lib().jova_gemm_set_bf16x3(0 if os.environ.get("JOVA_GEMM_NO_BF16X3") else 1)
+    if dist_on:
+        tf_ = torch.tensor([elapsed_f], dtype=torch.float64, device=device)
+        if shared:
+            trainer.reduce(tf_)
+            elapsed_f = float(tf_.item()) / world
+        else:
+            torch.distributed.all_reduce(tf_, op=torch.distributed.ReduceOp.MAX)
+            elapsed_f = float(tf_.item())
     # the same K steps with collation INSIDE the timed region: every batch is merged (native jova_collate_gconv), packed
     # into pinned memory and uploaded by the prefetch thread while the previous step runs
     n_cyc = len(batches)
@@ -461,12 +482,15 @@ def main():
                 value=round(pairs_per_s, 1), unit="pairs/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                 ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
                 vs_baseline=None, dtype="f32", data="synthetic",
+                dtype_note="fp32 operands and results everywhere; forward products on fp32 MFMA; backward products (dX, dW) of a GFLOP or more as six bf16 x bf16 piece products of three-way split fp32 operands with fp32 accumulation (error vs fp64 equal to an fp32 FMA chain: tests/test_gpu_ops.py::test_backward_products_from_bf16_pieces_are_fp32_accurate); fp32_mfma_only = the same steps with those products on fp32 MFMA too",
                 config=dict(workload=workload_text,
                             global_batch=bsz * world, parallelism="dp%d" % world,
                             trainable_params=count_parameters(model)),
                 final_loss=round(final_loss, 6), roofline=roofline)
     line["config"]["sampler"] = ("ShardSampler: %d-pair synthetic epoch, %d disjoint shards, %d steps/epoch, tail dropped"
                                  % (sampler.n_pairs, world, sampler.steps_per_epoch))
+    line["fp32_mfma_only"] = dict(value=round(args.steps * bsz * world / elapsed_f, 1), unit="pairs/s",
+                                  ms_per_step=round(elapsed_f / args.steps * 1e3, 3))
     line["with_collation"] = dict(
         value=round(args.steps * bsz * world / elapsed_c, 1), unit="pairs/s", ms_per_step=round(elapsed_c / args.steps * 1e3, 3),
         ratio_to_resident=round(elapsed / elapsed_c, 4),

@@ -125,6 +125,12 @@ int jova_nonsat_fwd(const float* x, int64_t n, float ep, int max_iter, float* ou
 /* spin bound of the barrier above in ticks of the 100 MHz wall clock (0 restores the default, 2 s); process-wide.
  * No counterpart in the reference; tests use it to provoke the give-up path. */
 void jova_nonsat_set_spin_limit(uint64_t ticks);
+/* Backward products of nn.Linear (dX = dY W, dW = dY^T X; torch autograd of proj/dti/train_joint_attn.py:460-466) of a
+ * GFLOP or more on aligned shapes run on the bf16 matrix pipe at fp32 accuracy: operands split into three bf16 pieces,
+ * six piece products, fp32 accumulation (jova_gemm_f32 / jova_linear_bwd_weight choose it by themselves; forward
+ * products never take it).  on = 0 keeps them on the fp32 MFMA kernel, as does JOVA_GEMM_NO_BF16X3 in the environment;
+ * process-wide.  No counterpart in the reference. */
+void jova_gemm_set_bf16x3(int on);
 /* Allocation-free variant of jova_nonsat_fwd.  NO counterpart in the reference: it exists for callers that cannot
  * allocate device memory (code under hipGraph capture, tight serving loops, harnesses that forbid hipMalloc).  Same
  * kernels and results as jova_nonsat_fwd, but the workspace lives in a built-in per-GPU scratch array of

@@ -61,7 +61,7 @@ _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "q": ctypes.c_int64, "f": ctypes
 
 EXPORTS = sorted(list(_SIGS) + ["jova_last_error", "jova_abi_version", "jova_nonsat_workspace_bytes",
                                 "jova_graphconv_workspace_floats", "jova_graphconv_bwd_scratch_floats",
-                                "jova_nonsat_set_spin_limit", "jova_nonsat_noalloc_max_n"])
+                                "jova_nonsat_set_spin_limit", "jova_nonsat_noalloc_max_n", "jova_gemm_set_bf16x3"])
 
 _lib = None
 
@@ -91,6 +91,8 @@ def lib():
         L.jova_nonsat_noalloc_max_n.argtypes = []
         L.jova_nonsat_set_spin_limit.restype = None
         L.jova_nonsat_set_spin_limit.argtypes = [ctypes.c_uint64]
+        L.jova_gemm_set_bf16x3.restype = None
+        L.jova_gemm_set_bf16x3.argtypes = [ctypes.c_int]
         _lib = L
     return _lib
 

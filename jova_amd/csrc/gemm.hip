@@ -802,6 +802,10 @@ gemm_bf16x3_kernel(X3Args xa) {
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// backward products on the bf16 matrix pipe (gemm_bf16x3_kernel): -1 = not decided yet (environment), 0 / 1
+static int g_bf16x3 = -1;
+extern "C" void jova_gemm_set_bf16x3(int on) { g_bf16x3 = on ? 1 : 0; }
+
 // csum / csum_done: the column sums of A, if the form that runs can add them up on the way (aligned form, A row-contiguous)
 static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
                      float* C, int64_t ldc, int M, int N, int K, float alpha, const float* bias,
@@ -849,11 +853,10 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
     // dX / dW of 30 848 x 2048 x 512: 568 / 533 -> 446 / 417 us; x 512 x 2048: 591 / 527 -> 468 / 406; x 1536 x 512: 424 / 416
     // -> 332 / 324; x 512 x 512: 151 / 153 -> 128 / 123; 23 168 x 256 x 256: 43 / 46 -> 41 / 40 (tools/x3_shapes.py).
     // JOVA_GEMM_NO_BF16X3 keeps everything on the fp32 MFMA kernel.
-    static int x3_env = -1, x3_all = 0;
-    if (x3_env < 0) {
-        x3_env = getenv("JOVA_GEMM_NO_BF16X3") ? 0 : 1;
-        x3_all = getenv("JOVA_GEMM_BF16X3_ALL") ? 1 : 0;              // (measurements: every aligned backward shape)
-    }
+    static int x3_all = -1;
+    if (x3_all < 0) x3_all = getenv("JOVA_GEMM_BF16X3_ALL") ? 1 : 0;              // (measurements: every aligned backward shape)
+    if (g_bf16x3 < 0) g_bf16x3 = getenv("JOVA_GEMM_NO_BF16X3") ? 0 : 1;
+    const int x3_env = g_bf16x3;
     if (x3_env && fast_env && nb1 == 1 && nb2 == 1 && !b_kc && M % 128 == 0 && N % 128 == 0 && K % XBK == 0 && K > 0 && va && vb &&
         (x3_all || (long long)M * N * K >= (1ll << 30)) && (splitk == 1 || ldc == N)) {
         X3Args xa;

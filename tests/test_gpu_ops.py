@@ -87,6 +87,38 @@ def test_linear_bwd_weight_fuses_the_bias_gradient(device, shape):
     H.assert_close(dw2, want_dw, tol=2e-6, what="dw (no bias)")
 
 
+@pytest.mark.parametrize("mode", ["plain", "relu_mask", "residual"])
+def test_backward_products_from_bf16_pieces_are_fp32_accurate(device, mode):
+    """dX = dY W of a GFLOP or more runs on the bf16 matrix pipe, every fp32 operand split into three bf16 pieces
+    (gemm_bf16x3_kernel).  Held to the error an fp32 FMA chain makes on the same product (measured here, against fp64), on
+    operands whose magnitudes spread over twelve decades; the ReLU-mask and residual epilogues are exact selections /
+    additions on top."""
+    from jova_amd.nn import functional as F_
+    M, N, K = 4096, 512, 1024                                     # dy [M, N], w [N, K] -> dx [M, K]; contraction over N
+    g = torch.Generator().manual_seed(31)
+    dy = torch.randn(M, N, generator=g) * torch.exp(6.0 * torch.randn(M, 1, generator=g))       # rows of very different size
+    w = torch.randn(N, K, generator=g) * torch.exp(3.0 * torch.randn(1, K, generator=g))
+    ref64 = dy.double() @ w.double()
+    fp32_chain = torch.zeros(M, K)
+    for n0 in range(0, N, 1):                                     # one fp32 rounding per term, in contraction order
+        fp32_chain += dy[:, n0:n0 + 1] * w[n0:n0 + 1, :]
+    scale = ref64.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)       # per output row: the rows differ by decades
+    err32 = ((fp32_chain.double() - ref64).abs() / scale).max().item()
+    extra = torch.randn(M, K, generator=g)
+    dyd, wd, dx = dy.to(device), w.to(device), torch.full((M, K), float("nan"), device=device)
+    if mode == "plain":
+        F_.linear_bwd_data(dyd, wd, dx)
+        want = ref64
+    elif mode == "relu_mask":
+        F_.linear_bwd_data(dyd, wd, dx, relu_mask=extra.to(device))
+        want = torch.where(extra.double() > 0, ref64, torch.zeros_like(ref64))
+    else:
+        F_.linear_bwd_data(dyd, wd, dx, residual=(extra * scale.float()).to(device))
+        want = ref64 + (extra * scale.float()).double()
+    err = ((dx.cpu().double() - want).abs() / scale).max().item()
+    assert err <= max(2e-6, 1.5 * err32), "bf16-pieces product: %.3e of the row scale, fp32 chain %.3e" % (err, err32)
+
+
 @pytest.mark.parametrize("shape", [(241, 241, 256, 32, 2), (256, 203, 64, 64, 1), (130, 250, 16, 3, 40)])
 def test_gemm_ragged_batched_aligned_form(device, shape):
     """The per-(b,h) attention products with K = head_dim (scores = Q K^T, dP = dO V^T) take the aligned kernel although S
