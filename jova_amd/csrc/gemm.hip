@@ -626,12 +626,12 @@ gemm_f32_fast_kernel(FastArgs fa) {
 // (tools/scratch/gemm_bf16x3_lab.hip: K = 512: 5.9e-7 against 8.2e-7 of max|C|; K = 2048: 2.0e-6 against 1.5e-6).
 // Used for the BACKWARD products only (dX = dY W and dW = dY^T X: B row-contiguous): the forward products stay on the fp32
 // MFMA kernels, so every forward value -- and with it every ReLU mask -- is what it was.
-// 128 x 128 output tile, 4 waves of 64 x 64, k-tiles of 32: global (fp32) -> registers -> split -> LDS ([piece][row][k],
-// 80-byte rows: the 16-byte fragment reads of 16 lanes cover all banks once) while the MFMAs of the previous k-tile run;
-// a row-contiguous operand is read as 4 x 4 blocks per thread and transposed in registers on its way to LDS.
+// 128 x 128 output tile, 4 waves of 64 x 64, k16 slabs through two LDS buffers: global (fp32) -> registers (two slabs in
+// flight) -> split -> LDS ([buffer][piece][row][k]) in the same basic block as the MFMAs of the slab before, one barrier per
+// slab; a row-contiguous operand is read as 4 (k) x 2 (rows) blocks per thread and transposed in registers on its way.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-constexpr int XBK = 32, XLD = 40;
+constexpr int XBK = 32;
 
 struct X3Args {
     GemmArgs g;
@@ -653,52 +653,48 @@ __device__ __forceinline__ void split4(const float v[4], bf16x4& h, bf16x4& m, b
     }
 }
 
-// 8-byte k-chunk c of row r sits at chunk c ^ x3_swz(r) (even values: a fragment's 16-byte chunk pair stays together and
-// in order): the transposing store of a row-contiguous operand (32 lanes on rows 4 apart, 320 bytes) would otherwise hit
-// the same banks 8 times over
-__device__ __forceinline__ int x3_swz(int row) { return ((row >> 4) & 3) << 1; }
+// LDS: [buffer][piece][row][k16 slab], 48-byte rows (the 16-byte fragment reads of 16 lanes cover all banks once); the
+// two 16-byte halves of a row trade places on rows 16..31 mod 32, which halves the bank conflicts of the transposing
+// store of a row-contiguous operand (lanes on rows 2 apart, 96 bytes)
+constexpr int XLD16 = 24;
+__device__ __forceinline__ int x3_half(int row, int half) { return (half ^ ((row >> 4) & 1)) * 8; }
 
 template <bool KC>
-struct X3Operand {                      // one 128 x 32 operand tile: global -> registers -> three bf16 images in LDS
-    float r[4][4];
-    __device__ __forceinline__ void load(const float* base, long long ld, int row0, int k0, int tid) {
-        if (KC) {                       // element (row, k) at row * ld + k: 4 x (16 bytes of one row)
+struct X3Operand {                      // one 128 x 16 operand slab: global -> registers -> three bf16 images in LDS
+    // KC (element (row, k) at row * ld + k): thread = (row, half): 8 consecutive k of one row.
+    // !KC (element (row, k) at k * ld + row): thread = (row pair, k block): 4 k x 2 rows, transposed in registers.
+    __device__ static __forceinline__ void load(float (&r)[8], const float* base, long long ld, int row0, int k0, int tid) {
+        if (KC) {
+            const float* p = base + (long long)(row0 + (tid >> 1)) * ld + k0 + 8 * (tid & 1);
+            *reinterpret_cast<float4*>(&r[0]) = *reinterpret_cast<const float4*>(p);
+            *reinterpret_cast<float4*>(&r[4]) = *reinterpret_cast<const float4*>(p + 4);
+        } else {
+            const float* p = base + (long long)(k0 + 4 * (tid >> 6)) * ld + row0 + 2 * (tid & 63);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int f = tid + 256 * j, row = f >> 3, c4 = f & 7;
-                *reinterpret_cast<float4*>(r[j]) = *reinterpret_cast<const float4*>(base + (long long)(row0 + row) * ld + k0 + c4 * 4);
-            }
-        } else {                        // element (row, k) at k * ld + row: a 4 (k) x 4 (rows) block
-            const int nb = tid & 31, kb = tid >> 5;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                *reinterpret_cast<float4*>(r[kk]) =
-                    *reinterpret_cast<const float4*>(base + (long long)(k0 + 4 * kb + kk) * ld + row0 + 4 * nb);
+            for (int kk = 0; kk < 4; ++kk) *reinterpret_cast<float2*>(&r[2 * kk]) = *reinterpret_cast<const float2*>(p + kk * ld);
         }
     }
-    __device__ __forceinline__ void store(__bf16 (*s)[128][XLD], int tid) const {
+    __device__ static __forceinline__ void store(const float (&r)[8], __bf16 (*s)[128][XLD16], int tid) {
         if (KC) {
+            const int row = tid >> 1, c = x3_half(row, tid & 1);
+            bf16x4 a0, a1, a2, b0, b1, b2;
+            split4(&r[0], a0, a1, a2);
+            split4(&r[4], b0, b1, b2);
+            *reinterpret_cast<bf16x8*>(&s[0][row][c]) = __builtin_shufflevector(a0, b0, 0, 1, 2, 3, 4, 5, 6, 7);
+            *reinterpret_cast<bf16x8*>(&s[1][row][c]) = __builtin_shufflevector(a1, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            *reinterpret_cast<bf16x8*>(&s[2][row][c]) = __builtin_shufflevector(a2, b2, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else {
+            const int kb = tid >> 6;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int f = tid + 256 * j, row = f >> 3, c4 = f & 7;
+            for (int j = 0; j < 2; ++j) {
+                const int row = 2 * (tid & 63) + j;
+                const float v[4] = {r[j], r[2 + j], r[4 + j], r[6 + j]};
                 bf16x4 p0, p1, p2;
-                split4(r[j], p0, p1, p2);
-                const int c = (c4 ^ x3_swz(row)) * 4;
+                split4(v, p0, p1, p2);
+                const int c = x3_half(row, kb >> 1) + 4 * (kb & 1);
                 *reinterpret_cast<bf16x4*>(&s[0][row][c]) = p0;
                 *reinterpret_cast<bf16x4*>(&s[1][row][c]) = p1;
                 *reinterpret_cast<bf16x4*>(&s[2][row][c]) = p2;
-            }
-        } else {
-            const int nb = tid & 31, kb = tid >> 5;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float v[4] = {r[0][j], r[1][j], r[2][j], r[3][j]};
-                bf16x4 p0, p1, p2;
-                split4(v, p0, p1, p2);
-                const int c = (kb ^ x3_swz(4 * nb + j)) * 4;
-                *reinterpret_cast<bf16x4*>(&s[0][4 * nb + j][c]) = p0;
-                *reinterpret_cast<bf16x4*>(&s[1][4 * nb + j][c]) = p1;
-                *reinterpret_cast<bf16x4*>(&s[2][4 * nb + j][c]) = p2;
             }
         }
     }
@@ -707,8 +703,8 @@ struct X3Operand {                      // one 128 x 32 operand tile: global -> 
 template <bool A_KC, bool B_KC>
 __global__ void __launch_bounds__(256, 2)
 gemm_bf16x3_kernel(X3Args xa) {
-    __shared__ __attribute__((aligned(16))) __bf16 sA[3][128][XLD];
-    __shared__ __attribute__((aligned(16))) __bf16 sB[3][128][XLD];
+    __shared__ __attribute__((aligned(16))) __bf16 sA[2][3][128][XLD16];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[2][3][128][XLD16];
     __shared__ float s_cs[128];
     const GemmArgs& g = xa.g;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
@@ -716,6 +712,7 @@ gemm_bf16x3_kernel(X3Args xa) {
     const int tile = blockIdx.x % tiles, part = blockIdx.x / tiles;
     const int m0 = (tile / xa.ntn) * 128, n0 = (tile % xa.ntn) * 128;
     const int kt0 = part * xa.per, nk = min(xa.per, xa.nk_total - kt0);
+    const int kbase = kt0 * XBK, ns = 2 * nk;               // k16 slabs of this part (even)
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const bool do_cs = !A_KC && g.csum != nullptr && n0 == 0;
     f32x16 acc[2][2];
@@ -725,49 +722,58 @@ gemm_bf16x3_kernel(X3Args xa) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    float cs[2] = {0.f, 0.f};
     if (tid < 128) s_cs[tid] = 0.f;
-    X3Operand<A_KC> oa;
-    X3Operand<B_KC> ob;
     const long long lda = A_KC ? g.sam : g.sak, ldb = B_KC ? g.sbn : g.sbk;
-    oa.load(g.A, lda, m0, kt0 * XBK, tid);
-    ob.load(g.B, ldb, n0, kt0 * XBK, tid);
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                         // every wave is past its fragment reads of the previous k-tile
-        if (do_cs) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) cs[j] += (oa.r[0][j] + oa.r[1][j]) + (oa.r[2][j] + oa.r[3][j]);
-        }
-        oa.store(sA, tid);
-        ob.store(sB, tid);
-        __syncthreads();
-        if (kt + 1 < nk) {                       // the next k-tile travels while this one is multiplied
-            oa.load(g.A, lda, m0, (kt0 + kt + 1) * XBK, tid);
-            ob.load(g.B, ldb, n0, (kt0 + kt + 1) * XBK, tid);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[3][2], fb[3][2];
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    fa[p][t] = *reinterpret_cast<const bf16x8*>(&sA[p][wm + 32 * t + i][((ks * 4 + 2 * h) ^ x3_swz(wm + 32 * t + i)) * 4]);
-                    fb[p][t] = *reinterpret_cast<const bf16x8*>(&sB[p][wn + 32 * t + i][((ks * 4 + 2 * h) ^ x3_swz(wn + 32 * t + i)) * 4]);
-                }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {    // small terms first
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][a], fb[2][b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][a], fb[0][b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][a], fb[1][b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][a], fb[1][b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][a], fb[0][b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][a], fb[0][b], acc[a][b], 0, 0, 0);
-                }
-        }
+    float ra[2][8], rb[2][8];                               // two slabs in flight (slot = slab & 1)
+    // One slab: the split + store of slab s+1 and the request for slab s+3 sit in the SAME basic block as the MFMAs of
+    // slab s (no branch in the body: past the end the stale registers go into the idle buffer and the last slab is asked
+    // for again), one barrier per slab.
+#define X3_LOAD(SL, s_)                                                                       \
+    do {                                                                                      \
+        X3Operand<A_KC>::load(ra[SL], g.A, lda, m0, kbase + 16 * (s_), tid);                  \
+        X3Operand<B_KC>::load(rb[SL], g.B, ldb, n0, kbase + 16 * (s_), tid);                  \
+    } while (0)
+#define X3_STORE(SL, BUF, s_)                                                                 \
+    do {                                                                                      \
+        if (!A_KC) {                                                                          \
+            const bool live = do_cs && (s_) < ns;                                             \
+            cs[0] += live ? (ra[SL][0] + ra[SL][2]) + (ra[SL][4] + ra[SL][6]) : 0.f;          \
+            cs[1] += live ? (ra[SL][1] + ra[SL][3]) + (ra[SL][5] + ra[SL][7]) : 0.f;          \
+        }                                                                                     \
+        X3Operand<A_KC>::store(ra[SL], sA[BUF], tid);                                         \
+        X3Operand<B_KC>::store(rb[SL], sB[BUF], tid);                                         \
+    } while (0)
+#define X3_STEP(CUR, s_)                                                                      \
+    do {                                                                                      \
+        X3_STORE(1 - CUR, 1 - CUR, (s_) + 1);                                                 \
+        X3_LOAD(1 - CUR, min((s_) + 3, ns - 1));                                              \
+        bf16x8 fa[3][2], fb[3][2];                                                            \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p)                                         \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                   \
+                fa[p][t] = *reinterpret_cast<const bf16x8*>(&sA[CUR][p][wm + 32 * t + i][x3_half(wm + 32 * t + i, h)]); \
+                fb[p][t] = *reinterpret_cast<const bf16x8*>(&sB[CUR][p][wn + 32 * t + i][x3_half(wn + 32 * t + i, h)]); \
+            }                                                                                 \
+        /* small terms first; the four accumulators take turns, so consecutive MFMAs are independent */ \
+        _Pragma("unroll") for (int t = 0; t < 6; ++t)                                         \
+            _Pragma("unroll") for (int a = 0; a < 2; ++a)                                     \
+                _Pragma("unroll") for (int b = 0; b < 2; ++b)                                 \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][a], fb[PB[t]][b], acc[a][b], 0, 0, 0); \
+        __syncthreads();                                                                      \
+    } while (0)
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+    X3_LOAD(0, 0);
+    X3_LOAD(1, 1);
+    X3_STORE(0, 0, 0);
+    X3_LOAD(0, min(2, ns - 1));
+    __syncthreads();
+    for (int s_i = 0; s_i < ns; s_i += 2) {
+        X3_STEP(0, s_i);
+        X3_STEP(1, s_i + 1);
     }
+#undef X3_LOAD
+#undef X3_STORE
+#undef X3_STEP
     const bool first = part == 0, partial = g.splitk > 1;       // split-K by contract ADDS onto C, even as a single part
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -791,10 +797,9 @@ gemm_bf16x3_kernel(X3Args xa) {
                 }
             }
         }
-    if (do_cs) {                                 // (A row-contiguous: thread (nb, kb) carried rows 4 nb .. 4 nb + 3)
-        const int nb = tid & 31;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) atomicAdd(&s_cs[4 * nb + j], cs[j]);
+    if (do_cs) {                                 // (A row-contiguous: thread (row pair, k block) carried rows 2 p, 2 p + 1)
+        atomicAdd(&s_cs[2 * (tid & 63)], cs[0]);
+        atomicAdd(&s_cs[2 * (tid & 63) + 1], cs[1]);
         __syncthreads();
         if (tid < 128) atomicAdd(&g.csum[m0 + tid], s_cs[tid]);
     }

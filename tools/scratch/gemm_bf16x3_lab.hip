@@ -121,6 +121,111 @@ gemm_bf16x3_kernel(const float* __restrict__ A, const float* __restrict__ B, flo
             }
 }
 
+// v2: k16 slabs, two LDS buffers, ONE barrier per slab: the split + store of slab s+1 sits in the same basic block as
+// the MFMAs of slab s, so the scheduler can put the VALU / LDS-write work into the MFMA shadow of the same wave.
+constexpr int LD16 = 24;                                    // 48-byte rows: conflict-free 16-byte fragment reads
+__device__ __forceinline__ void split8(const float4 x0, const float4 x1, bf16x8& h, bf16x8& m, bf16x8& l) {
+    const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 hi = (__bf16)v[i];
+        const float r1 = v[i] - bf16_up(hi);
+        const __bf16 mi = (__bf16)r1;
+        h[i] = hi;
+        m[i] = mi;
+        l[i] = (__bf16)(r1 - bf16_up(mi));
+    }
+}
+__global__ void __launch_bounds__(256, 2)
+gemm_bf16x3_v2_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) __bf16 sA[2][3][BM][LD16];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[2][3][BN][LD16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int ntn = N / BN;
+    const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int row = tid >> 1, half = tid & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float4 ra[2][2], rb[2][2];                              // two slabs in flight (slot = slab & 1)
+    const float* Ap = A + (long long)(m0 + row) * K + 8 * half;
+    const float* Bp = B + (long long)(n0 + row) * K + 8 * half;
+#define GLOAD(SL, s_)                                                                   \
+    do {                                                                                \
+        ra[SL][0] = *reinterpret_cast<const float4*>(Ap + (s_) * 16);                   \
+        ra[SL][1] = *reinterpret_cast<const float4*>(Ap + (s_) * 16 + 4);               \
+        rb[SL][0] = *reinterpret_cast<const float4*>(Bp + (s_) * 16);                   \
+        rb[SL][1] = *reinterpret_cast<const float4*>(Bp + (s_) * 16 + 4);               \
+    } while (0)
+#define LSTORE(SL, buf)                                                                 \
+    do {                                                                                \
+        bf16x8 p0, p1, p2;                                                              \
+        split8(ra[SL][0], ra[SL][1], p0, p1, p2);                                       \
+        *reinterpret_cast<bf16x8*>(&sA[buf][0][row][8 * half]) = p0;                    \
+        *reinterpret_cast<bf16x8*>(&sA[buf][1][row][8 * half]) = p1;                    \
+        *reinterpret_cast<bf16x8*>(&sA[buf][2][row][8 * half]) = p2;                    \
+        split8(rb[SL][0], rb[SL][1], p0, p1, p2);                                       \
+        *reinterpret_cast<bf16x8*>(&sB[buf][0][row][8 * half]) = p0;                    \
+        *reinterpret_cast<bf16x8*>(&sB[buf][1][row][8 * half]) = p1;                    \
+        *reinterpret_cast<bf16x8*>(&sB[buf][2][row][8 * half]) = p2;                    \
+    } while (0)
+#define STEP(CUR, s_)                                                                   \
+    do {                                                                                \
+        LSTORE(1 - CUR, 1 - CUR);       /* (past the end: stale registers into the idle buffer) */ \
+        GLOAD(1 - CUR, min((s_) + 3, ns - 1)); /* branch-free body: one basic block for the scheduler */ \
+        bf16x8 fa[3][2], fb[3][2];                                                      \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p)                                   \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t) {                             \
+                fa[p][t] = *reinterpret_cast<const bf16x8*>(&sA[CUR][p][wm + 32 * t + i][8 * h]); \
+                fb[p][t] = *reinterpret_cast<const bf16x8*>(&sB[CUR][p][wn + 32 * t + i][8 * h]); \
+            }                                                                           \
+        _Pragma("unroll") for (int t = 0; t < 6; ++t)                                   \
+            _Pragma("unroll") for (int a = 0; a < 2; ++a)                               \
+                _Pragma("unroll") for (int b = 0; b < 2; ++b)                           \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][a], fb[PB[t]][b], acc[a][b], 0, 0, 0); \
+        SCHED_HINT                                                                      \
+        __syncthreads();                                                                \
+    } while (0)
+#ifdef LAB_SCHED
+#define SCHED_HINT                                                                      \
+    _Pragma("unroll") for (int q = 0; q < 24; ++q) {                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              \
+        __builtin_amdgcn_sched_group_barrier(0x002, LAB_SCHED, 0);                      \
+        if ((q & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);            \
+    }
+#else
+#define SCHED_HINT
+#endif
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+    const int ns = K / 16;                                  // even (K % 32 == 0)
+    GLOAD(0, 0);
+    LSTORE(0, 0);
+    GLOAD(1, 1);
+    GLOAD(0, min(2, ns - 1));
+    __syncthreads();
+    for (int s = 0; s < ns; s += 2) {
+        STEP(0, s);
+        STEP(1, s + 1);
+    }
+#undef GLOAD
+#undef LSTORE
+#undef STEP
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                C[(long long)m * N + n0 + wn + 32 * b + i] = acc[a][b][r];
+            }
+}
+
 // plain fp32 FMA reference on the device for a sample of rows (one thread per output), summed in k order
 __global__ void ref_rows_kernel(const float* A, const float* B, float* Cr, double* Cd, int N, int K, const int* rows, int nrows) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -173,10 +278,11 @@ int main(int argc, char** argv) {
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     const dim3 grid((M / BM) * (N / BN));
-    for (int variant = 0; variant < 2; ++variant) {
+    for (int variant = 0; variant < 3; ++variant) {
         auto launch = [&]() {
             if (variant == 0) hipLaunchKernelGGL(gemm_bf16x3_kernel<6>, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
-            else hipLaunchKernelGGL(gemm_bf16x3_kernel<3>, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
+            else if (variant == 1) hipLaunchKernelGGL(gemm_bf16x3_kernel<3>, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
+            else hipLaunchKernelGGL(gemm_bf16x3_v2_kernel, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
         };
         for (int w = 0; w < 20; ++w) launch();
         CHECK(hipDeviceSynchronize());
@@ -193,8 +299,8 @@ int main(int argc, char** argv) {
             CHECK(hipMemcpy(hC.data() + (size_t)r * N, dC + (size_t)rows[r] * N, sizeof(float) * N, hipMemcpyDeviceToHost));
         }
         for (size_t e = 0; e < hCd.size(); ++e) err = fmax(err, fabs((double)hC[e] - hCd[e]));
-        printf("%d piece products: %8.1f us  %7.1f TFLOP/s (fp32-equivalent)   vs fp64: max err / max|C| = %.3e\n",
-               variant == 0 ? 6 : 3, us, 2.0 * M * N * K / us * 1e-6, err / scale);
+        printf("%s%d piece products: %8.1f us  %7.1f TFLOP/s (fp32-equivalent)   vs fp64: max err / max|C| = %.3e\n",
+               variant == 2 ? "v2 " : "", variant == 1 ? 3 : 6, us, 2.0 * M * N * K / us * 1e-6, err / scale);
     }
     return 0;
 }
