@@ -709,7 +709,12 @@ gemm_bf16x3_kernel(X3Args xa) {
     const GemmArgs& g = xa.g;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
     const int tiles = xa.ntm * xa.ntn;
-    const int tile = blockIdx.x % tiles, part = blockIdx.x / tiles;
+    int slot = blockIdx.x;               // workgroups b, b + 8, ... share an XCD: give each XCD a contiguous run of work items
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = slot & 7, loc = slot >> 3;
+        slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tile = slot % tiles, part = slot / tiles;
     const int m0 = (tile / xa.ntn) * 128, n0 = (tile % xa.ntn) * 128;
     const int kt0 = part * xa.per, nk = min(xa.per, xa.nk_total - kt0);
     const int kbase = kt0 * XBK, ns = 2 * nk;               // k16 slabs of this part (even)
