@@ -6,7 +6,7 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Kernel_Name"].startsw
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 line = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
 steps, warm = line["steps"], line["warmup"]
-total_steps = 2 * (steps + warm)                     # resident run, then the run with collation in the loop
+total_steps = 2 * (steps + warm) + steps + min(warm, 2)   # resident run, fp32-MFMA-only run, run with collation in the loop
 per_step = len(rows) // total_steps
 assert per_step * total_steps == len(rows), (len(rows), total_steps)
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000.0 for r in rows]
