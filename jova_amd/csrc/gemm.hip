@@ -865,9 +865,11 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
     // JOVA_GEMM_NO_BF16X3 keeps everything on the fp32 MFMA kernel.
     static int x3_all = -1;
     if (x3_all < 0) x3_all = getenv("JOVA_GEMM_BF16X3_ALL") ? 1 : 0;              // (measurements: every aligned backward shape)
+    static int x3_fwd = -1;
+    if (x3_fwd < 0) x3_fwd = getenv("JOVA_GEMM_BF16X3_FWD") ? 1 : 0;              // (experiment: forward products too)
     if (g_bf16x3 < 0) g_bf16x3 = getenv("JOVA_GEMM_NO_BF16X3") ? 0 : 1;
     const int x3_env = g_bf16x3;
-    if (x3_env && fast_env && nb1 == 1 && nb2 == 1 && !b_kc && M % 128 == 0 && N % 128 == 0 && K % XBK == 0 && K > 0 && va && vb &&
+    if (x3_env && fast_env && nb1 == 1 && nb2 == 1 && (!b_kc || (x3_fwd && a_kc)) && M % 128 == 0 && N % 128 == 0 && K % XBK == 0 && K > 0 && va && vb &&
         (x3_all || (long long)M * N * K >= (1ll << 30)) && (splitk == 1 || ldc == N)) {
         X3Args xa;
         xa.g = g;
@@ -882,7 +884,8 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
         }
         const long long nwg = (long long)xa.ntm * xa.ntn * xa.parts;
         JOVA_CHECK_ARG(nwg < (1ll << 31), "gemm: too many tiles");
-        if (a_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), dim3((unsigned)nwg), dim3(256), 0, s, xa);
+        if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), dim3((unsigned)nwg), dim3(256), 0, s, xa);
+        else if (a_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), dim3((unsigned)nwg), dim3(256), 0, s, xa);
         else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), dim3((unsigned)nwg), dim3(256), 0, s, xa);
         JOVA_CHECK_LAUNCH("gemm_bf16x3");
         return JOVA_OK;
