@@ -237,16 +237,28 @@ layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ r, c
     ln_load<LNV, VEC4>(gamma, d, lane, gm);
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = min(n_rows, r0 + rows_per_block);
-    for (long long row = r0 + wave; row < r1; row += 4) {
-        const float mean = mean_rstd[2 * row], rstd = mean_rstd[2 * row + 1];
-        float z[LNV], t[LNV], dyv[LNV];
-        ln_load<LNV, VEC4>(x + row * d, d, lane, z);
-        if (r) {
-            ln_load<LNV, VEC4>(r + row * d, d, lane, t);
-#pragma unroll
-            for (int k = 0; k < LNV; ++k) z[k] += t[k];
+    // the next row's three loads are in flight while this row's two wave reductions run (one row per wave at a time left
+    // the kernel at 4.6 TB/s: latency-bound)
+    float nz[LNV], nt[LNV], ndy[LNV], nmean = 0.f, nrstd = 0.f;
+    auto fetch = [&](long long row) {
+        if (row < r1) {
+            nmean = mean_rstd[2 * row];
+            nrstd = mean_rstd[2 * row + 1];
+            ln_load<LNV, VEC4>(x + row * d, d, lane, nz);
+            if (r) ln_load<LNV, VEC4>(r + row * d, d, lane, nt);
+            ln_load<LNV, VEC4>(dy + row * d, d, lane, ndy);
         }
-        ln_load<LNV, VEC4>(dy + row * d, d, lane, dyv);
+    };
+    fetch(r0 + wave);
+    for (long long row = r0 + wave; row < r1; row += 4) {
+        const float mean = nmean, rstd = nrstd;
+        float z[LNV], t[LNV], dyv[LNV];
+#pragma unroll
+        for (int k = 0; k < LNV; ++k) {
+            z[k] = r ? nz[k] + nt[k] : nz[k];
+            dyv[k] = ndy[k];
+        }
+        fetch(row + 4);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < LNV; ++k) {
