@@ -67,7 +67,8 @@ def test_gemm_few_tiles_long_k_is_split_with_bias(device, shape):
 
 
 @pytest.mark.parametrize("shape", [(3840, 2048, 512), (1280, 512, 512), (256, 128, 128), (640, 242, 242), (77, 22, 512),
-                                   (23168, 512, 22), (4099, 22, 242), (2048, 22, 22), (2500, 1, 300), (6000, 32, 512)])
+                                   (23168, 512, 22), (4099, 22, 242), (2048, 22, 22), (2500, 1, 300), (6000, 32, 512),
+                                   (128, 4096, 2048)])          # (the last: bf16-pieces form without split-K, dw through the residual)
 def test_linear_bwd_weight_fuses_the_bias_gradient(device, shape):
     """jova_linear_bwd_weight: dw += dy^T x and db += colsum(dy), both ACCUMULATING, on the aligned form (bias gradient
     summed from the product's own A fragments, with and without split-K) and on the generic form (separate pass); one side <= 32 wide over >= 2048 rows takes the streaming reduction."""
