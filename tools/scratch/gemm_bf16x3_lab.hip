@@ -136,6 +136,20 @@ __device__ __forceinline__ void split8(const float4 x0, const float4 x1, bf16x8&
         l[i] = (__bf16)(r1 - bf16_up(mi));
     }
 }
+// diagnostics (wrong results on purpose, same memory traffic): LAB_NOSPLIT = one conversion instead of the three-level
+// split; LAB_NOSTORE = no split and no LDS stores; LAB_NOREAD = fragments read once, outside the loop
+#ifdef LAB_NOSPLIT
+__device__ __forceinline__ void cheap8(const float4 x0, const float4 x1, bf16x8& h, bf16x8& m, bf16x8& l) {
+    const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (__bf16)v[i];
+    m = h;
+    l = h;
+}
+#define SPLIT8 cheap8
+#else
+#define SPLIT8 split8
+#endif
 __global__ void __launch_bounds__(256, 2)
 gemm_bf16x3_v2_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K) {
     __shared__ __attribute__((aligned(16))) __bf16 sA[2][3][BM][LD16];
@@ -155,6 +169,33 @@ gemm_bf16x3_v2_kernel(const float* __restrict__ A, const float* __restrict__ B, 
     float4 ra[2][2], rb[2][2];                              // two slabs in flight (slot = slab & 1)
     const float* Ap = A + (long long)(m0 + row) * K + 8 * half;
     const float* Bp = B + (long long)(n0 + row) * K + 8 * half;
+#ifdef LAB_MAP4
+    // four lanes per row (64 contiguous bytes), rows r and r + 64 per thread: a load instruction touches 16 rows instead of 32
+    const int rq = tid >> 2, cq = tid & 3;
+    const float* Aq = A + (long long)(m0 + rq) * K + 4 * cq;
+    const float* Bq = B + (long long)(n0 + rq) * K + 4 * cq;
+#define GLOAD(SL, s_)                                                                   \
+    do {                                                                                \
+        ra[SL][0] = *reinterpret_cast<const float4*>(Aq + (s_) * 16);                   \
+        ra[SL][1] = *reinterpret_cast<const float4*>(Aq + 64ll * K + (s_) * 16);        \
+        rb[SL][0] = *reinterpret_cast<const float4*>(Bq + (s_) * 16);                   \
+        rb[SL][1] = *reinterpret_cast<const float4*>(Bq + 64ll * K + (s_) * 16);        \
+    } while (0)
+#define LSTORE(SL, buf)                                                                 \
+    do {                                                                                \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                 \
+            bf16x4 p0, p1, p2;                                                          \
+            split4(ra[SL][j], p0, p1, p2);                                              \
+            *reinterpret_cast<bf16x4*>(&sA[buf][0][rq + 64 * j][4 * cq]) = p0;          \
+            *reinterpret_cast<bf16x4*>(&sA[buf][1][rq + 64 * j][4 * cq]) = p1;          \
+            *reinterpret_cast<bf16x4*>(&sA[buf][2][rq + 64 * j][4 * cq]) = p2;          \
+            split4(rb[SL][j], p0, p1, p2);                                              \
+            *reinterpret_cast<bf16x4*>(&sB[buf][0][rq + 64 * j][4 * cq]) = p0;          \
+            *reinterpret_cast<bf16x4*>(&sB[buf][1][rq + 64 * j][4 * cq]) = p1;          \
+            *reinterpret_cast<bf16x4*>(&sB[buf][2][rq + 64 * j][4 * cq]) = p2;          \
+        }                                                                               \
+    } while (0)
+#else
 #define GLOAD(SL, s_)                                                                   \
     do {                                                                                \
         ra[SL][0] = *reinterpret_cast<const float4*>(Ap + (s_) * 16);                   \
@@ -162,28 +203,44 @@ gemm_bf16x3_v2_kernel(const float* __restrict__ A, const float* __restrict__ B, 
         rb[SL][0] = *reinterpret_cast<const float4*>(Bp + (s_) * 16);                   \
         rb[SL][1] = *reinterpret_cast<const float4*>(Bp + (s_) * 16 + 4);               \
     } while (0)
+#if defined(LAB_NOSTORE)
+#define LSTORE(SL, buf) do { dummy += ra[SL][0].x + ra[SL][1].w + rb[SL][0].y + rb[SL][1].z; } while (0)
+#else
 #define LSTORE(SL, buf)                                                                 \
     do {                                                                                \
         bf16x8 p0, p1, p2;                                                              \
-        split8(ra[SL][0], ra[SL][1], p0, p1, p2);                                       \
+        SPLIT8(ra[SL][0], ra[SL][1], p0, p1, p2);                                       \
         *reinterpret_cast<bf16x8*>(&sA[buf][0][row][8 * half]) = p0;                    \
         *reinterpret_cast<bf16x8*>(&sA[buf][1][row][8 * half]) = p1;                    \
         *reinterpret_cast<bf16x8*>(&sA[buf][2][row][8 * half]) = p2;                    \
-        split8(rb[SL][0], rb[SL][1], p0, p1, p2);                                       \
+        SPLIT8(rb[SL][0], rb[SL][1], p0, p1, p2);                                       \
         *reinterpret_cast<bf16x8*>(&sB[buf][0][row][8 * half]) = p0;                    \
         *reinterpret_cast<bf16x8*>(&sB[buf][1][row][8 * half]) = p1;                    \
         *reinterpret_cast<bf16x8*>(&sB[buf][2][row][8 * half]) = p2;                    \
     } while (0)
-#define STEP(CUR, s_)                                                                   \
-    do {                                                                                \
-        LSTORE(1 - CUR, 1 - CUR);       /* (past the end: stale registers into the idle buffer) */ \
-        GLOAD(1 - CUR, min((s_) + 3, ns - 1)); /* branch-free body: one basic block for the scheduler */ \
-        bf16x8 fa[3][2], fb[3][2];                                                      \
+#endif
+#endif   /* LAB_MAP4 */
+#define FRAG_READ_DO(CUR)                                                               \
         _Pragma("unroll") for (int p = 0; p < 3; ++p)                                   \
             _Pragma("unroll") for (int t = 0; t < 2; ++t) {                             \
                 fa[p][t] = *reinterpret_cast<const bf16x8*>(&sA[CUR][p][wm + 32 * t + i][8 * h]); \
                 fb[p][t] = *reinterpret_cast<const bf16x8*>(&sB[CUR][p][wn + 32 * t + i][8 * h]); \
-            }                                                                           \
+            }
+#ifdef LAB_NOREAD
+#define FRAG_READ(CUR)
+#else
+#define FRAG_READ(CUR) FRAG_READ_DO(CUR)
+#endif
+#ifdef LAB_NOLOAD
+#define GLOAD_LOOP(SL, s_) do { } while (0)
+#else
+#define GLOAD_LOOP(SL, s_) GLOAD(SL, s_)
+#endif
+#define STEP(CUR, s_)                                                                   \
+    do {                                                                                \
+        LSTORE(1 - CUR, 1 - CUR);       /* (past the end: stale registers into the idle buffer) */ \
+        GLOAD_LOOP(1 - CUR, min((s_) + 3, ns - 1)); /* branch-free body: one basic block for the scheduler */ \
+        FRAG_READ(CUR)                                                                  \
         _Pragma("unroll") for (int t = 0; t < 6; ++t)                                   \
             _Pragma("unroll") for (int a = 0; a < 2; ++a)                               \
                 _Pragma("unroll") for (int b = 0; b < 2; ++b)                           \
@@ -202,12 +259,17 @@ gemm_bf16x3_v2_kernel(const float* __restrict__ A, const float* __restrict__ B, 
 #define SCHED_HINT
 #endif
     constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+    bf16x8 fa[3][2], fb[3][2];
+    float dummy = 0.f;
     const int ns = K / 16;                                  // even (K % 32 == 0)
     GLOAD(0, 0);
     LSTORE(0, 0);
     GLOAD(1, 1);
     GLOAD(0, min(2, ns - 1));
     __syncthreads();
+#ifdef LAB_NOREAD
+    FRAG_READ_DO(0)
+#endif
     for (int s = 0; s < ns; s += 2) {
         STEP(0, s);
         STEP(1, s + 1);
@@ -215,6 +277,7 @@ gemm_bf16x3_v2_kernel(const float* __restrict__ A, const float* __restrict__ B, 
 #undef GLOAD
 #undef LSTORE
 #undef STEP
+    if (dummy == 123.456f) acc[0][0][0] += dummy;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
