@@ -467,6 +467,88 @@ gemm_bf16x3_v4_kernel(const float* __restrict__ A, const float* __restrict__ B, 
             }
 }
 
+// v5: v2 with 32-byte LDS rows (halves swapped on rows 8..15 mod 16: conflict-free fragment reads) = 49 KB per workgroup,
+// and at most 168 VGPRs: THREE workgroups per CU to cover the per-slab dependency chain.
+__device__ __forceinline__ int swz5(int row, int half) { return (half ^ ((row >> 3) & 1)) * 8; }
+__global__ void __launch_bounds__(256, 3)
+gemm_bf16x3_v5_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) __bf16 sA[2][3][BM][16];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[2][3][BN][16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int ntn = N / BN;
+    const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int row = tid >> 1, half = tid & 1, wpos = swz5(row, half);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float4 ra[2][2], rb[2][2];
+    const float* Ap = A + (long long)(m0 + row) * K + 8 * half;
+    const float* Bp = B + (long long)(n0 + row) * K + 8 * half;
+#define GLOAD5(SL, s_)                                                                  \
+    do {                                                                                \
+        ra[SL][0] = *reinterpret_cast<const float4*>(Ap + (s_) * 16);                   \
+        ra[SL][1] = *reinterpret_cast<const float4*>(Ap + (s_) * 16 + 4);               \
+        rb[SL][0] = *reinterpret_cast<const float4*>(Bp + (s_) * 16);                   \
+        rb[SL][1] = *reinterpret_cast<const float4*>(Bp + (s_) * 16 + 4);               \
+    } while (0)
+#define LSTORE5(SL, buf)                                                                \
+    do {                                                                                \
+        bf16x8 p0, p1, p2;                                                              \
+        split8(ra[SL][0], ra[SL][1], p0, p1, p2);                                       \
+        *reinterpret_cast<bf16x8*>(&sA[buf][0][row][wpos]) = p0;                        \
+        *reinterpret_cast<bf16x8*>(&sA[buf][1][row][wpos]) = p1;                        \
+        *reinterpret_cast<bf16x8*>(&sA[buf][2][row][wpos]) = p2;                        \
+        split8(rb[SL][0], rb[SL][1], p0, p1, p2);                                       \
+        *reinterpret_cast<bf16x8*>(&sB[buf][0][row][wpos]) = p0;                        \
+        *reinterpret_cast<bf16x8*>(&sB[buf][1][row][wpos]) = p1;                        \
+        *reinterpret_cast<bf16x8*>(&sB[buf][2][row][wpos]) = p2;                        \
+    } while (0)
+#define STEP5(CUR, s_)                                                                  \
+    do {                                                                                \
+        LSTORE5(1 - CUR, 1 - CUR);                                                      \
+        GLOAD5(1 - CUR, min((s_) + 3, ns - 1));                                         \
+        bf16x8 fa[3][2], fb[3][2];                                                      \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p)                                   \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t) {                             \
+                fa[p][t] = *reinterpret_cast<const bf16x8*>(&sA[CUR][p][wm + 32 * t + i][swz5(wm + 32 * t + i, h)]); \
+                fb[p][t] = *reinterpret_cast<const bf16x8*>(&sB[CUR][p][wn + 32 * t + i][swz5(wn + 32 * t + i, h)]); \
+            }                                                                           \
+        _Pragma("unroll") for (int t = 0; t < 6; ++t)                                   \
+            _Pragma("unroll") for (int a = 0; a < 2; ++a)                               \
+                _Pragma("unroll") for (int b = 0; b < 2; ++b)                           \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][a], fb[PB[t]][b], acc[a][b], 0, 0, 0); \
+        __syncthreads();                                                                \
+    } while (0)
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+    const int ns = K / 16;
+    GLOAD5(0, 0);
+    GLOAD5(1, 1);
+    LSTORE5(0, 0);
+    GLOAD5(0, min(2, ns - 1));
+    __syncthreads();
+    for (int s = 0; s < ns; s += 2) {
+        STEP5(0, s);
+        STEP5(1, s + 1);
+    }
+#undef GLOAD5
+#undef LSTORE5
+#undef STEP5
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                C[(long long)m * N + n0 + wn + 32 * b + i] = acc[a][b][r];
+            }
+}
+
 // plain fp32 FMA reference on the device for a sample of rows (one thread per output), summed in k order
 __global__ void ref_rows_kernel(const float* A, const float* B, float* Cr, double* Cd, int N, int K, const int* rows, int nrows) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -519,13 +601,14 @@ int main(int argc, char** argv) {
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     const dim3 grid((M / BM) * (N / BN));
-    for (int variant = 0; variant < 5; ++variant) {
+    for (int variant = 0; variant < 6; ++variant) {
         auto launch = [&]() {
             if (variant == 0) hipLaunchKernelGGL(gemm_bf16x3_kernel<6>, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
             else if (variant == 1) hipLaunchKernelGGL(gemm_bf16x3_kernel<3>, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
             else if (variant == 2) hipLaunchKernelGGL(gemm_bf16x3_v2_kernel, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
             else if (variant == 3) hipLaunchKernelGGL(gemm_bf16x3_v3_kernel, grid, dim3(512), 0, 0, dA, dB, dC, M, N, K);
-            else hipLaunchKernelGGL(gemm_bf16x3_v4_kernel, dim3(((M + 255) / 256) * (N / 128)), dim3(512), 0, 0, dA, dB, dC, M, N, K);
+            else if (variant == 4) hipLaunchKernelGGL(gemm_bf16x3_v4_kernel, dim3(((M + 255) / 256) * (N / 128)), dim3(512), 0, 0, dA, dB, dC, M, N, K);
+            else hipLaunchKernelGGL(gemm_bf16x3_v5_kernel, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
         };
         for (int w = 0; w < 20; ++w) launch();
         CHECK(hipDeviceSynchronize());
@@ -543,7 +626,7 @@ int main(int argc, char** argv) {
         }
         for (size_t e = 0; e < hCd.size(); ++e) err = fmax(err, fabs((double)hC[e] - hCd[e]));
         printf("%s%d piece products: %8.1f us  %7.1f TFLOP/s (fp32-equivalent)   vs fp64: max err / max|C| = %.3e\n",
-               variant == 2 ? "v2 " : (variant == 3 ? "v3 " : (variant == 4 ? "v4 " : "")), variant == 1 ? 3 : 6, us, 2.0 * M * N * K / us * 1e-6, err / scale);
+               variant == 2 ? "v2 " : (variant == 3 ? "v3 " : (variant == 4 ? "v4 " : (variant == 5 ? "v5 " : ""))), variant == 1 ? 3 : 6, us, 2.0 * M * N * K / us * 1e-6, err / scale);
     }
     return 0;
 }
