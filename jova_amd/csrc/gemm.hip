@@ -348,7 +348,27 @@ __device__ unsigned long long gemm_probe[4 * 1024];     // dev-only: per workgro
 // RAG (both operands K-contiguous): a batch of matrices (nb2, strides s?1 / s?2 of GemmArgs) whose M and N need not be
 // multiples of 128 -- edge tiles read clamped rows and store guarded; used for the per-(b,h) attention products with
 // K = 256 (scores = Q K^T and dP = dO V^T), which otherwise run on the generic form at 0.6 of this one's rate.
-template <bool A_KC, bool B_KC, bool RAG = false>
+// X3: the k-tile's fp32 fragments (the same LDS reads) are split into three bf16 pieces each in registers and multiplied
+// as six v_mfma_f32_32x32x16_bf16 per accumulator (see "fp32 from bf16 pieces" below): the operands still travel by LDS-DMA
+// as fp32, nothing is stored to LDS from registers, and the whole persistent machinery (XCD order, split-K, ragged last
+// round, column sums) is this kernel's.  The 8 k of a lane's bf16 fragment are the two 4-k groups the fp32 form reads for
+// MFMA groups 0 and 1 -- the same permutation of k for A and B, which only changes the summation order.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+__device__ __forceinline__ void split8_regs(const float (&lo)[4], const float (&hi)[4], bf16x8_t (&p)[3]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = j < 4 ? lo[j] : hi[j - 4];
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - __uint_as_float(((unsigned)(*reinterpret_cast<const unsigned short*>(&h))) << 16);
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - __uint_as_float(((unsigned)(*reinterpret_cast<const unsigned short*>(&m))) << 16);
+        p[0][j] = h;
+        p[1][j] = m;
+        p[2][j] = (__bf16)r2;
+    }
+}
+
+template <bool A_KC, bool B_KC, bool RAG = false, bool X3 = false>
 __global__ void __launch_bounds__(256, FWGS)
 gemm_f32_fast_kernel(FastArgs fa) {
 #ifdef GEMM_CLOCK_PROBE
@@ -486,6 +506,27 @@ gemm_f32_fast_kernel(FastArgs fa) {
         Frag f0, f1;
         load_frag(f0, st, 0);
         load_frag(f1, st, 1);
+        if (X3) {
+            if (!A_KC && do_cs) {
+                cs0 += ((f0.a0[0] + f0.a0[1]) + (f0.a0[2] + f0.a0[3])) + ((f1.a0[0] + f1.a0[1]) + (f1.a0[2] + f1.a0[3]));
+                cs1 += ((f0.a1[0] + f0.a1[1]) + (f0.a1[2] + f0.a1[3])) + ((f1.a1[0] + f1.a1[1]) + (f1.a1[2] + f1.a1[3]));
+            }
+            bf16x8_t pa[2][3], pb[2][3];
+            split8_regs(f0.a0, f1.a0, pa[0]);
+            split8_regs(f0.a1, f1.a1, pa[1]);
+            split8_regs(f0.b0, f1.b0, pb[0]);
+            split8_regs(f0.b1, f1.b1, pb[1]);
+            // small terms first; the four accumulators take turns, so consecutive MFMAs are independent
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][PA[t]], pb[b][PB[t]], acc[a][b], 0, 0, 0);
+            return;
+        }
         __builtin_amdgcn_sched_barrier(0);
         mfma16(f0);
         __builtin_amdgcn_sched_barrier(0);
@@ -869,8 +910,14 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
     if (x3_fwd < 0) x3_fwd = getenv("JOVA_GEMM_BF16X3_FWD") ? 1 : 0;              // (experiment: forward products too)
     if (g_bf16x3 < 0) g_bf16x3 = getenv("JOVA_GEMM_NO_BF16X3") ? 0 : 1;
     const int x3_env = g_bf16x3;
-    if (x3_env && fast_env && nb1 == 1 && nb2 == 1 && (!b_kc || (x3_fwd && a_kc)) && M % 128 == 0 && N % 128 == 0 && K % XBK == 0 && K > 0 && va && vb &&
-        (x3_all || (long long)M * N * K >= (1ll << 30)) && (splitk == 1 || ldc == N)) {
+    static int x3_old = -1;
+    if (x3_old < 0) x3_old = getenv("JOVA_GEMM_BF16X3_OLD") ? 1 : 0;              // (A/B: the register-staged kernel)
+    const bool x3_want = x3_env && fast_env && nb1 == 1 && nb2 == 1 && (!b_kc || (x3_fwd && a_kc)) && M % 128 == 0 && N % 128 == 0 &&
+                         K % XBK == 0 && K > 0 && va && vb && (x3_all || (long long)M * N * K >= (1ll << 30)) &&
+                         (splitk == 1 || ldc == N);
+    // dW (both operands row-contiguous) on the register-staged kernel (262-290 us against 292-332 us), dX (A K-contiguous)
+    // on the LDS-DMA form of the persistent kernel (338 us against 364 us on average): kernel trace of the Davis step
+    if (x3_want && (x3_old || !a_kc)) {
         X3Args xa;
         xa.g = g;
         xa.ntm = M / 128;
@@ -972,7 +1019,11 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
             }
         }
         const int nwg = fa.items < slots ? fa.items : slots;
-#define GEMM_FAST(AK, BK_) hipLaunchKernelGGL((gemm_f32_fast_kernel<AK, BK_>), dim3(nwg), dim3(256), 0, s, fa)
+#define GEMM_FAST(AK, BK_)                                                                                          \
+    do {                                                                                                            \
+        if (x3_want) hipLaunchKernelGGL((gemm_f32_fast_kernel<AK, BK_, false, true>), dim3(nwg), dim3(256), 0, s, fa);  \
+        else hipLaunchKernelGGL((gemm_f32_fast_kernel<AK, BK_>), dim3(nwg), dim3(256), 0, s, fa);                   \
+    } while (0)
         if (a_kc && b_kc) GEMM_FAST(true, true);
         else if (a_kc && !b_kc) GEMM_FAST(true, false);
         else if (!a_kc && b_kc) GEMM_FAST(false, true);
