@@ -118,6 +118,17 @@ def test_backward_products_from_bf16_pieces_are_fp32_accurate(device, mode):
         want = ref64 + (extra * scale.float()).double()
     err = ((dx.cpu().double() - want).abs() / scale).max().item()
     assert err <= max(2e-6, 1.5 * err32), "bf16-pieces product: %.3e of the row scale, fp32 chain %.3e" % (err, err32)
+    if mode == "plain":                                           # the switch: same product on the fp32 MFMA kernel
+        from jova_amd._lib import lib
+        lib().jova_gemm_set_bf16x3(0)
+        try:
+            dx32 = torch.full((M, K), float("nan"), device=device)
+            F_.linear_bwd_data(dyd, wd, dx32)
+        finally:
+            lib().jova_gemm_set_bf16x3(1)
+        e32k = ((dx32.cpu().double() - want).abs() / scale).max().item()
+        assert e32k <= max(2e-6, 1.5 * err32), "fp32 MFMA kernel: %.3e" % e32k
+        assert not torch.equal(dx32, dx), "the switch changed nothing: both calls took the same kernel"
 
 
 @pytest.mark.parametrize("shape", [(241, 241, 256, 32, 2), (256, 203, 64, 64, 1), (130, 250, 16, 3, 40)])
