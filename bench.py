@@ -410,6 +410,7 @@ def main():
     # the same K steps with the backward products kept on the fp32 MFMA kernel (jova_gemm_set_bf16x3(0)): what the
     # bf16-pieces backward GEMM is worth, and the number to take if that form is not accepted as fp32 arithmetic
     from jova_amd._lib import lib as _jova_lib
+    x3_was = _jova_lib().jova_gemm_get_bf16x3()
     _jova_lib().jova_gemm_set_bf16x3(0)
     for i in range(min(args.warmup, 2)):
         trainer.step(batches[i % len(batches)])
@@ -419,7 +420,7 @@ def main():
         trainer.step(batches[i % len(batches)])
     sync_all()
     elapsed_f = time.perf_counter() - t3
-    _jova_lib().jova_gemm_set_bf16x3(0 if os.environ.get("JOVA_GEMM_NO_BF16X3") else 1)
+    _jova_lib().jova_gemm_set_bf16x3(x3_was)
     if dist_on:
         tf_ = torch.tensor([elapsed_f], dtype=torch.float64, device=device)
         if shared:

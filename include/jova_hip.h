@@ -94,14 +94,16 @@ int jova_adj_reverse_pos(int64_t n_atoms, const int64_t* deg_slice, const int32_
  * process_gconv_view_data, jova/data/data.py:290).  HOST-only, no GPU call; every pointer is a HOST pointer.
  * Per molecule m (atoms already degree-sorted as ConvMol.__init__ leaves them, mol_graphs.py:54-201): n_atoms[m],
  * feats[m] int64 [n, n_feat], deg_list[m] int64 [n] (non-decreasing), nbr_flat[m] int64 [sum deg] = the neighbour lists
- * in atom order, local ids.  Outputs (the caller's upload image, typically pinned): nodes [N, n_feat], deg_slice [11,2],
+ * in atom order, local ids, n_nbr[m] = length of nbr_flat[m] (checked against sum deg: an inconsistent molecule is an
+ * error, not a read past the array).  Outputs (the caller's upload image, typically pinned): nodes [N, n_feat], deg_slice [11,2],
  * membership [N], adj = adj_1 | .. | adj_10 concatenated (adj_d int32 [n_d, d]), mol_off int32 [n_mols + 1] (prefix sums
  * of n_atoms), block_order (optional, as jova_block_order), symmetric (optional: 1 iff the adjacency is a simple
  * undirected graph, the host counterpart of jova_adj_symmetry), atoms_f32 (optional: the fp32 copy of nodes with rows
  * zero padded to ld_f32 floats, as jova_atoms_to_f32), rev_pos (optional, uint8 [sum_d n_d * d], as
  * jova_adj_reverse_pos).  Same integers as the reference, bit for bit. */
 int jova_collate_gconv(int n_mols, const int32_t* n_atoms, const int64_t* const* feats, const int64_t* const* deg_list,
-                       const int64_t* const* nbr_flat, int n_feat, int64_t* nodes_out, int64_t* deg_slice_out,
+                       const int64_t* const* nbr_flat, const int64_t* n_nbr, int n_feat, int64_t* nodes_out,
+                       int64_t* deg_slice_out,
                        int64_t* membership_out, int32_t* adj_out, int32_t* mol_off_out, int32_t* block_order_out_or_null,
                        int* symmetric_out_or_null, float* atoms_f32_out_or_null, int ld_f32,
                        uint8_t* rev_pos_out_or_null);
@@ -131,6 +133,8 @@ void jova_nonsat_set_spin_limit(uint64_t ticks);
  * products never take it).  on = 0 keeps them on the fp32 MFMA kernel, as does JOVA_GEMM_NO_BF16X3 in the environment;
  * process-wide.  No counterpart in the reference. */
 void jova_gemm_set_bf16x3(int on);
+/* the switch's current value (1 = on), the environment default resolved: lets a caller put back what it found */
+int jova_gemm_get_bf16x3(void);
 /* Allocation-free variant of jova_nonsat_fwd.  NO counterpart in the reference: it exists for callers that cannot
  * allocate device memory (code under hipGraph capture, tight serving loops, harnesses that forbid hipMalloc).  Same
  * kernels and results as jova_nonsat_fwd, but the workspace lives in a built-in per-GPU scratch array of
@@ -217,20 +221,32 @@ int jova_viewpool_bwd(const float* dout, const int32_t* seg_off, int n_views, in
 /* ---- loss and optimiser step: proj/dti/train_joint_attn.py:464-465, :485-486 ---------------------------------- */
 int jova_mse_loss(const float* outputs, const float* weights, const float* target, int n, float* loss,
                   float* dout_or_null, void* stream);
-int jova_sgd_step(float* params, const float* grads, float* momentum_buf_or_null, int64_t n, float lr,
-                  float weight_decay, float momentum, float grad_scale, int first_step, void* stream);
-int jova_adamax_step(float* params, const float* grads, float* exp_avg, float* exp_inf, int64_t n, float lr,
-                     float beta1, float beta2, float eps, float weight_decay, float grad_scale, int step, void* stream);
+/* Optimizer steps (torch.optim semantics on the flat buffers).  Common tail of the three entry points:
+ * skip_flag_or_null = the device flag of jova_nonfinite_flag: while it is non-zero parameters and optimizer state are
+ * left untouched (the reference leaves its loop at a NaN loss before backward / optimizer.step, :468-470, so its
+ * weights stay at the last finite values; here that decision needs no device->host read); zero_grads != 0 clears the
+ * gradient buffer once it has been consumed (optimizer.zero_grad() of the next step, :428, without a second pass). */
+int jova_sgd_step(float* params, float* grads, float* momentum_buf_or_null, int64_t n, float lr,
+                  float weight_decay, float momentum, float grad_scale, int first_step,
+                  const int* skip_flag_or_null, int zero_grads, void* stream);
+int jova_adamax_step(float* params, float* grads, float* exp_avg, float* exp_inf, int64_t n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, float grad_scale, int step,
+                     const int* skip_flag_or_null, int zero_grads, void* stream);
 
-/* torch.optim.Adam / RMSprop / Adagrad / Adadelta (the optimizer table of proj/dti/train_joint_attn.py:276-285) on the flat
- * parameter / gradient buffers.  kind 2 = adam (h0 beta1, h1 beta2, h2 eps; state1 exp_avg, state2 exp_avg_sq),
+/* torch.optim.Adam / RMSprop / Adagrad / Adadelta / ASGD / Rprop (with sgd and adamax above: the whole optimizer table of
+ * proj/dti/train_joint_attn.py:276-285) on the flat parameter / gradient buffers.
+ * kind 2 = adam (h0 beta1, h1 beta2, h2 eps; state1 exp_avg, state2 exp_avg_sq),
  * 3 = rmsprop (h0 alpha, h1 eps, h2 momentum; state1 square_avg, state2 momentum buffer or NULL when h2 == 0),
- * 4 = adagrad (h0 lr_decay, h1 eps; state1 sum), 5 = adadelta (h0 rho, h1 eps; state1 square_avg, state2 acc_delta).
+ * 4 = adagrad (h0 lr_decay, h1 eps; state1 sum), 5 = adadelta (h0 rho, h1 eps; state1 square_avg, state2 acc_delta),
+ * 6 = asgd (h0 lambd, h1 alpha, h2 t0; state1 ax = the averaged iterate; eta and mu follow from `step`),
+ * 7 = rprop (h0 eta-, h1 eta+, h3 / h4 smallest / largest step size; state1 previous gradient, state2 per-element step
+ *     size, initialised to lr by the caller; weight_decay must be 0).
  * step = 1-based step count; gradient used = grads * grad_scale + weight_decay * params. */
-int jova_optim_step(int kind, float* params, const float* grads, float* state1, float* state2_or_null, int64_t n,
-                    float lr, float weight_decay, float grad_scale, int step, float h0, float h1, float h2, void* stream);
-/* *flag |= 1 if x holds a NaN or an infinity: the fail-fast of proj/dti/train_joint_attn.py:468-470 without a
- * device->host read per batch */
+int jova_optim_step(int kind, float* params, float* grads, float* state1, float* state2_or_null, int64_t n,
+                    float lr, float weight_decay, float grad_scale, int step, float h0, float h1, float h2, float h3,
+                    float h4, const int* skip_flag_or_null, int zero_grads, void* stream);
+/* *flag |= 1 if x holds a NaN, |= 2 if it holds an infinity: the fail-fast of proj/dti/train_joint_attn.py:468-470
+ * (which tests for NaN) without a device->host read per batch */
 int jova_nonfinite_flag(const float* x, int64_t n, int* flag, void* stream);
 
 /* dst[r][c] (+)= src[r][c] inside the source's extent, 0 outside, for r < dst_rows, c < dst_cols (row strides ld_*): pads
@@ -287,6 +303,9 @@ int jova_dti_metrics(const float* y_true, const float* y_pred, const float* w_or
 int jova_relu_fwd(const float* x, int64_t n, float* y, void* stream);
 int jova_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* stream);
 int jova_axpy(const float* x, float a, int64_t n, float* y, void* stream);
+/* p[0..n) = 0 as a kernel on the stream (optimizer.zero_grad(), proj/dti/train_joint_attn.py:428, on the flat gradient
+ * buffer; a kernel rather than a memset so that it replays reliably inside a captured hipGraph) */
+int jova_zero(float* p, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

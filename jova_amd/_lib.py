@@ -17,7 +17,7 @@ _SIGS = {
     "jova_atoms_to_f32": "pqiipp",
     "jova_graphconv_bwd": "piqqiippp" + "pppp" + "ppppppp",
     "jova_adj_symmetry": "qpppp",
-    "jova_collate_gconv": "ipppp" + "i" + "ppppppp" + "pip",
+    "jova_collate_gconv": "ippppp" + "i" + "ppppppp" + "pip",
     "jova_graphpool_fwd": "pqipp" + "pppp",
     "jova_block_order": "pqp",
     "jova_graphpool_bwd": "ppqipp" + "ppippp",
@@ -42,9 +42,9 @@ _SIGS = {
     "jova_viewpool_fwd": "ppiiipp",
     "jova_viewpool_bwd": "ppiiiipp",
     "jova_mse_loss": "pppippp",
-    "jova_sgd_step": "pppq" + "ffffi" + "p",
-    "jova_adamax_step": "ppppq" + "ffffffi" + "p",
-    "jova_optim_step": "ipppp" + "qfffi" + "fffp",
+    "jova_sgd_step": "pppq" + "ffffi" + "pip",
+    "jova_adamax_step": "ppppq" + "ffffffi" + "pip",
+    "jova_optim_step": "ipppp" + "qfffi" + "fffff" + "pip",
     "jova_nonfinite_flag": "pqpp",
     "jova_dti_metrics": "pppi" + "dd" + "ppp",
     "jova_copy2d": "pqiqpqiqip", "jova_linear_bwd_weight": "pqpqqiippip",
@@ -55,13 +55,14 @@ _SIGS = {
     "jova_relu_fwd": "pqpp",
     "jova_relu_bwd": "ppqpp",
     "jova_axpy": "pfqpp",
+    "jova_zero": "pqp",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "q": ctypes.c_int64, "f": ctypes.c_float, "Q": ctypes.c_uint64,
        "d": ctypes.c_double}
 
 EXPORTS = sorted(list(_SIGS) + ["jova_last_error", "jova_abi_version", "jova_nonsat_workspace_bytes",
                                 "jova_graphconv_workspace_floats", "jova_graphconv_bwd_scratch_floats",
-                                "jova_nonsat_set_spin_limit", "jova_nonsat_noalloc_max_n", "jova_gemm_set_bf16x3"])
+                                "jova_nonsat_set_spin_limit", "jova_nonsat_noalloc_max_n", "jova_gemm_set_bf16x3", "jova_gemm_get_bf16x3"])
 
 _lib = None
 
@@ -93,6 +94,8 @@ def lib():
         L.jova_nonsat_set_spin_limit.argtypes = [ctypes.c_uint64]
         L.jova_gemm_set_bf16x3.restype = None
         L.jova_gemm_set_bf16x3.argtypes = [ctypes.c_int]
+        L.jova_gemm_get_bf16x3.restype = ctypes.c_int
+        L.jova_gemm_get_bf16x3.argtypes = []
         _lib = L
     return _lib
 

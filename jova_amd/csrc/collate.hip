@@ -15,13 +15,14 @@
 #define CNB 11
 
 extern "C" int jova_collate_gconv(int n_mols, const int32_t* n_atoms, const int64_t* const* feats,
-                                  const int64_t* const* deg_list, const int64_t* const* nbr_flat, int n_feat,
+                                  const int64_t* const* deg_list, const int64_t* const* nbr_flat,
+                                  const int64_t* n_nbr, int n_feat,
                                   int64_t* nodes_out, int64_t* deg_slice_out, int64_t* membership_out,
                                   int32_t* adj_out, int32_t* mol_off_out, int32_t* block_order_out_or_null,
                                   int* symmetric_out_or_null, float* atoms_f32_out_or_null, int ld_f32,
                                   uint8_t* rev_pos_out_or_null) {
     JOVA_CHECK_ARG(n_mols >= 0 && n_feat >= 1 && deg_slice_out && mol_off_out, "collate_gconv: bad argument");
-    JOVA_CHECK_ARG(n_mols == 0 || (n_atoms && feats && deg_list && nbr_flat && nodes_out && membership_out && adj_out),
+    JOVA_CHECK_ARG(n_mols == 0 || (n_atoms && feats && deg_list && nbr_flat && n_nbr && nodes_out && membership_out && adj_out),
                    "collate_gconv: null pointer");
     // bucket sizes per molecule (deg_list is non-decreasing: atoms are degree-sorted inside a molecule)
     std::vector<int64_t> size((size_t)CNB * (n_mols > 0 ? n_mols : 1), 0);
@@ -30,13 +31,17 @@ extern "C" int jova_collate_gconv(int n_mols, const int32_t* n_atoms, const int6
     for (int m = 0; m < n_mols; ++m) {
         const int n = n_atoms[m];
         JOVA_CHECK_ARG(n >= 0, "collate_gconv: molecule %d has %d atoms", m, n);
-        int64_t prev = 0;
+        int64_t prev = 0, deg_sum = 0;
         for (int a = 0; a < n; ++a) {
             const int64_t d = deg_list[m][a];
             JOVA_CHECK_ARG(d >= prev && d < CNB, "collate_gconv: molecule %d: degrees must be sorted and <= 10", m);
             prev = d;
+            deg_sum += d;
             ++size[(size_t)d * n_mols + m];
         }
+        // the neighbour lists are read below up to sum(deg): an inconsistent molecule must not run past its array
+        JOVA_CHECK_ARG(deg_sum == n_nbr[m], "collate_gconv: molecule %d: degrees sum to %lld but nbr_flat holds %lld entries",
+                       m, (long long)deg_sum, (long long)n_nbr[m]);
         total += n;
         JOVA_CHECK_ARG(total < (1ll << 31), "collate_gconv: more than 2^31 atoms");
         mol_off_out[m + 1] = (int32_t)total;

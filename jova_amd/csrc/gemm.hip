@@ -507,6 +507,8 @@ gemm_f32_fast_kernel(FastArgs fa) {
         load_frag(f0, st, 0);
         load_frag(f1, st, 1);
         if (X3) {
+            // the bf16-pieces body consumes exactly the two 8-k fragment groups of a 16-deep k-tile
+            static_assert(!X3 || FBK == 16, "gemm_f32_fast_kernel<X3>: the bf16-pieces branch needs FBK == 16");
             if (!A_KC && do_cs) {
                 cs0 += ((f0.a0[0] + f0.a0[1]) + (f0.a0[2] + f0.a0[3])) + ((f1.a0[0] + f1.a0[1]) + (f1.a0[2] + f1.a0[3]));
                 cs1 += ((f0.a1[0] + f0.a1[1]) + (f0.a1[2] + f0.a1[3])) + ((f1.a1[0] + f1.a1[1]) + (f1.a1[2] + f1.a1[3]));
@@ -855,7 +857,12 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 
 // backward products on the bf16 matrix pipe (gemm_bf16x3_kernel): -1 = not decided yet (environment), 0 / 1
 static int g_bf16x3 = -1;
+static int bf16x3_state() {
+    if (g_bf16x3 < 0) g_bf16x3 = getenv("JOVA_GEMM_NO_BF16X3") ? 0 : 1;
+    return g_bf16x3;
+}
 extern "C" void jova_gemm_set_bf16x3(int on) { g_bf16x3 = on ? 1 : 0; }
+extern "C" int jova_gemm_get_bf16x3(void) { return bf16x3_state(); }
 
 // csum / csum_done: the column sums of A, if the form that runs can add them up on the way (aligned form, A row-contiguous)
 static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
@@ -908,8 +915,7 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
     if (x3_all < 0) x3_all = getenv("JOVA_GEMM_BF16X3_ALL") ? 1 : 0;              // (measurements: every aligned backward shape)
     static int x3_fwd = -1;
     if (x3_fwd < 0) x3_fwd = getenv("JOVA_GEMM_BF16X3_FWD") ? 1 : 0;              // (experiment: forward products too)
-    if (g_bf16x3 < 0) g_bf16x3 = getenv("JOVA_GEMM_NO_BF16X3") ? 0 : 1;
-    const int x3_env = g_bf16x3;
+    const int x3_env = bf16x3_state();
     static int x3_old = -1;
     if (x3_old < 0) x3_old = getenv("JOVA_GEMM_BF16X3_OLD") ? 1 : 0;              // (A/B: the register-staged kernel)
     const bool x3_want = x3_env && fast_env && nb1 == 1 && nb2 == 1 && (!b_kc || (x3_fwd && a_kc)) && M % 128 == 0 && N % 128 == 0 &&

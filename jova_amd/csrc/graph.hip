@@ -3883,13 +3883,33 @@ extern "C" int jova_nonsat_fwd_noalloc(const float* x, int64_t n, float ep, int 
                        "caller workspace", (long long)n, (long long)NS_NOALLOC_MAX_N);
         return JOVA_ERR_LIMIT;
     }
-    int dev = 0;
-    JOVA_CHECK_HIP(hipGetDevice(&dev));
+    // The scratch array is per GPU: it must be the copy of the GPU the work runs on, i.e. the device of `stream` and of
+    // the buffers -- not whatever device the calling thread has current.  A null stream runs on the current device; any
+    // other stream names its own.  The output buffer must live there too; a mismatch is an error, not a launch on GPU A
+    // with GPU B's scratch address.
+    int cur = 0, dev = 0;
+    JOVA_CHECK_HIP(hipGetDevice(&cur));
+    dev = cur;
+    if (stream) {
+        hipDevice_t sd = 0;
+        JOVA_CHECK_HIP(hipStreamGetDevice((hipStream_t)stream, &sd));
+        dev = (int)sd;
+    }
     JOVA_CHECK_ARG(dev >= 0 && dev < JOVA_MAX_DEVICES, "nonsat_fwd_noalloc: device %d out of range", dev);
+    {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, out) == hipSuccess && at.type == hipMemoryTypeDevice && at.device != dev) {
+            jova_set_error("nonsat_fwd_noalloc: `out` lives on GPU %d but the stream belongs to GPU %d", at.device, dev);
+            return JOVA_ERR_ARG;
+        }
+        (void)hipGetLastError();
+    }
+    JOVA_CHECK_ARG(dev == cur, "nonsat_fwd_noalloc: the stream belongs to GPU %d but GPU %d is current: make the stream's "
+                               "device current before the call", dev, cur);
     void* ws = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_scratch_mu);
-        if (!g_scratch_ptr[dev]) {               // first call on this device, with this device current
+        if (!g_scratch_ptr[dev]) {               // first call on this device, with this device current (checked above)
             void* p = nullptr;
             JOVA_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
             JOVA_CHECK_ARG(p != nullptr, "nonsat_fwd_noalloc: hipGetSymbolAddress returned null");

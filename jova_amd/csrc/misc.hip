@@ -162,31 +162,45 @@ mse_kernel(const float* __restrict__ o, const float* __restrict__ w, const float
 
 // ------------------------------------------------------------------------------------------------ optimiser
 // torch.optim.SGD(lr, momentum, weight_decay, nesterov=False): g += wd * p; buf = mu * buf + g; p -= lr * buf
-__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom, long long n,
-                           float lr, float wd, float mu, float gscale, int first) {
+// Every optimizer kernel takes two extras.  `skip`: device flag of jova_nonfinite_flag; when it is set the parameters
+// and the optimizer state are left as they are (the reference leaves its loop at a NaN loss BEFORE backward / step,
+// proj/dti/train_joint_attn.py:468-470, so its weights stay at the last finite values; here the decision stays on the
+// device).  `zero_g`: the gradient is cleared once it has been consumed, which spares the step a separate fill of the
+// flat gradient buffer (optimizer.zero_grad(), :428).
+__global__ void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ mom, long long n,
+                           float lr, float wd, float mu, float gscale, int first, const int* __restrict__ skip,
+                           int zero_g) {
+    const bool upd = !(skip && *skip);
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
          e += (long long)gridDim.x * blockDim.x) {
-        float d = g[e] * gscale + wd * p[e];
-        if (mom) {
-            d = first ? d : mu * mom[e] + d;
-            mom[e] = d;
+        if (upd) {
+            float d = g[e] * gscale + wd * p[e];
+            if (mom) {
+                d = first ? d : mu * mom[e] + d;
+                mom[e] = d;
+            }
+            p[e] -= lr * d;
         }
-        p[e] -= lr * d;
+        if (zero_g) g[e] = 0.f;
     }
 }
 
 // torch.optim.Adamax(lr, betas, eps, weight_decay): the reference's default optimiser when no tuned CSV is found
-__global__ void adamax_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__global__ void adamax_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                               float* __restrict__ u, long long n, float lr, float b1, float b2, float eps, float wd,
-                              float gscale, float bias_corr1) {
+                              float gscale, float bias_corr1, const int* __restrict__ skip, int zero_g) {
+    const bool upd = !(skip && *skip);
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
          e += (long long)gridDim.x * blockDim.x) {
-        const float d = g[e] * gscale + wd * p[e];
-        const float mm = b1 * m[e] + (1.f - b1) * d;
-        const float uu = fmaxf(b2 * u[e], fabsf(d) + eps);
-        m[e] = mm;
-        u[e] = uu;
-        p[e] -= (lr / bias_corr1) * mm / uu;
+        if (upd) {
+            const float d = g[e] * gscale + wd * p[e];
+            const float mm = b1 * m[e] + (1.f - b1) * d;
+            const float uu = fmaxf(b2 * u[e], fabsf(d) + eps);
+            m[e] = mm;
+            u[e] = uu;
+            p[e] -= (lr / bias_corr1) * mm / uu;
+        }
+        if (zero_g) g[e] = 0.f;
     }
 }
 
@@ -274,12 +288,15 @@ extern "C" int jova_mse_loss(const float* outputs, const float* weights, const f
 
 // adam / rmsprop / adagrad / adadelta on the flat buffers, torch.optim semantics (the reference builds its optimizer from
 // torch.optim by name, proj/dti/train_joint_attn.py:276-296); weight decay is the coupled L2 form (d = g + wd p)
-__global__ void optim_kernel(int kind, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ s1,
+__global__ void optim_kernel(int kind, float* __restrict__ p, float* __restrict__ g, float* __restrict__ s1,
                              float* __restrict__ s2, long long n, float lr, float wd, float gscale, float h0, float h1,
-                             float h2, float c0, float c1) {
+                             float h2, float c0, float c1, const int* __restrict__ skip, int zero_g) {
+    const bool upd = !(skip && *skip);
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
          e += (long long)gridDim.x * blockDim.x) {
-        const float d = g[e] * gscale + wd * p[e];
+        float d = g[e] * gscale + wd * p[e];
+        if (zero_g) g[e] = 0.f;
+        if (!upd) continue;
         if (kind == 2) {                         // adam: h0 = beta1, h1 = beta2, h2 = eps, c0 = 1 - b1^t, c1 = sqrt(1 - b2^t)
             const float m = h0 * s1[e] + (1.f - h0) * d;
             const float v = h1 * s2[e] + (1.f - h1) * d * d;
@@ -301,33 +318,63 @@ __global__ void optim_kernel(int kind, float* __restrict__ p, const float* __res
             const float sum = s1[e] + d * d;
             s1[e] = sum;
             p[e] -= c0 * d / (sqrtf(sum) + h1);
-        } else {                                 // adadelta: h0 = rho, h1 = eps (s1 = square_avg, s2 = acc_delta)
+        } else if (kind == 5) {                  // adadelta: h0 = rho, h1 = eps (s1 = square_avg, s2 = acc_delta)
             const float sq = h0 * s1[e] + (1.f - h0) * d * d;
             const float delta = sqrtf(s2[e] + h1) / sqrtf(sq + h1) * d;
             s1[e] = sq;
             s2[e] = h0 * s2[e] + (1.f - h0) * delta * delta;
             p[e] -= lr * delta;
+        } else if (kind == 6) {                  // asgd: h0 = eta_t, h1 = lambd, h2 = mu_t (s1 = ax, the averaged iterate)
+            float pn = p[e] * (1.f - h1 * h0);
+            pn = pn - h0 * d;
+            p[e] = pn;
+            const float ax = s1[e];
+            s1[e] = h2 != 1.f ? ax + (pn - ax) * h2 : pn;
+        } else {                                 // rprop: h0 = eta-, h1 = eta+, c0 / c1 = step size bounds (s1 = previous
+            const float prod = d * s1[e];        // gradient, s2 = per-element step size); no weight decay (wd = 0)
+            const float fac = prod > 0.f ? h1 : (prod < 0.f ? h0 : 1.f);
+            const float ss = fminf(fmaxf(s2[e] * fac, c0), c1);
+            s2[e] = ss;
+            if (prod < 0.f) d = 0.f;
+            const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            p[e] -= sg * ss;
+            s1[e] = d;
         }
     }
 }
 
-extern "C" int jova_optim_step(int kind, float* params, const float* grads, float* state1, float* state2_or_null,
+extern "C" int jova_optim_step(int kind, float* params, float* grads, float* state1, float* state2_or_null,
                                int64_t n, float lr, float weight_decay, float grad_scale, int step, float h0, float h1,
-                               float h2, void* stream) {
-    JOVA_CHECK_ARG(kind >= 2 && kind <= 5, "optim_step: kind %d (2 adam, 3 rmsprop, 4 adagrad, 5 adadelta)", kind);
+                               float h2, float h3, float h4, const int* skip_flag_or_null, int zero_grads, void* stream) {
+    JOVA_CHECK_ARG(kind >= 2 && kind <= 7,
+                   "optim_step: kind %d (2 adam, 3 rmsprop, 4 adagrad, 5 adadelta, 6 asgd, 7 rprop)", kind);
     JOVA_CHECK_ARG(n >= 0 && step >= 1 && (n == 0 || (params && grads && state1)), "optim_step: bad argument");
     if (n == 0) return JOVA_OK;
-    JOVA_CHECK_ARG(state2_or_null || kind == 4 || (kind == 3 && h2 <= 0.f), "optim_step: this optimizer needs state2");
-    if (n == 0) return JOVA_OK;
+    JOVA_CHECK_ARG(state2_or_null || kind == 4 || kind == 6 || (kind == 3 && h2 <= 0.f),
+                   "optim_step: this optimizer needs state2");
     float c0 = 1.f, c1 = 1.f;
     if (kind == 2) {
         c0 = (float)(1.0 - pow((double)h0, (double)step));
         c1 = (float)sqrt(1.0 - pow((double)h1, (double)step));
     } else if (kind == 4) {
         c0 = (float)((double)lr / (1.0 + (double)(step - 1) * (double)h0));
+    } else if (kind == 6) {
+        // torch.optim.ASGD: eta and mu are functions of the step count alone (its state tensors `eta`, `mu`):
+        // eta_t = lr / (1 + lambd lr (t-1))^alpha, mu_t = 1 / max(1, (t-1) - t0); h0 lambd, h1 alpha, h2 t0
+        const double lambd = h0, alpha = h1, t0 = h2, tm1 = (double)(step - 1);
+        const double eta = (double)lr / pow(1.0 + lambd * (double)lr * tm1, alpha);
+        const double mu = 1.0 / fmax(1.0, tm1 - t0);
+        h0 = (float)eta;
+        h1 = (float)lambd;
+        h2 = (float)mu;
+    } else if (kind == 7) {
+        JOVA_CHECK_ARG(weight_decay == 0.f, "optim_step: rprop takes no weight decay");
+        c0 = h3;                                 // step_sizes = (min, max)
+        c1 = h4;
     }
     hipLaunchKernelGGL(optim_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, kind, params, grads, state1,
-                       state2_or_null, (long long)n, lr, weight_decay, grad_scale, h0, h1, h2, c0, c1);
+                       state2_or_null, (long long)n, lr, weight_decay, grad_scale, h0, h1, h2, c0, c1, skip_flag_or_null,
+                       zero_grads);
     JOVA_CHECK_LAUNCH("optim_step");
     return JOVA_OK;
 }
@@ -335,10 +382,12 @@ extern "C" int jova_optim_step(int kind, float* params, const float* grads, floa
 // flag |= 1 if any of x[0..n) is NaN or infinite (the reference's fail-fast reads loss.item() every batch,
 // train_joint_attn.py:468-470; here the flag stays on the device and is read once per epoch)
 __global__ void nonfinite_flag_kernel(const float* __restrict__ x, long long n, int* __restrict__ flag) {
-    bool bad = false;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
-        bad = bad || !isfinite(x[e]);
-    if (bad) atomicOr(flag, 1);
+    int bad = 0;                                 // bit 0: a NaN (what the reference tests for), bit 1: an infinity
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const float v = x[e];
+        bad |= (v != v) ? 1 : (isinf(v) ? 2 : 0);
+    }
+    if (bad) atomicOr(flag, bad);
 }
 extern "C" int jova_nonfinite_flag(const float* x, int64_t n, int* flag, void* stream) {
     JOVA_CHECK_ARG(flag && n >= 0 && (n == 0 || x), "nonfinite_flag: bad argument");
@@ -348,24 +397,27 @@ extern "C" int jova_nonfinite_flag(const float* x, int64_t n, int* flag, void* s
     return JOVA_OK;
 }
 
-extern "C" int jova_sgd_step(float* params, const float* grads, float* momentum_buf_or_null, int64_t n, float lr,
-                             float weight_decay, float momentum, float grad_scale, int first_step, void* stream) {
+extern "C" int jova_sgd_step(float* params, float* grads, float* momentum_buf_or_null, int64_t n, float lr,
+                             float weight_decay, float momentum, float grad_scale, int first_step,
+                             const int* skip_flag_or_null, int zero_grads, void* stream) {
     JOVA_CHECK_ARG(params && grads && n >= 0, "sgd_step: bad argument");
     if (n == 0) return JOVA_OK;
     hipLaunchKernelGGL(sgd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, params, grads,
-                       momentum_buf_or_null, (long long)n, lr, weight_decay, momentum, grad_scale, first_step);
+                       momentum_buf_or_null, (long long)n, lr, weight_decay, momentum, grad_scale, first_step,
+                       skip_flag_or_null, zero_grads);
     JOVA_CHECK_LAUNCH("sgd_step");
     return JOVA_OK;
 }
 
-extern "C" int jova_adamax_step(float* params, const float* grads, float* exp_avg, float* exp_inf, int64_t n, float lr,
+extern "C" int jova_adamax_step(float* params, float* grads, float* exp_avg, float* exp_inf, int64_t n, float lr,
                                 float beta1, float beta2, float eps, float weight_decay, float grad_scale, int step,
-                                void* stream) {
+                                const int* skip_flag_or_null, int zero_grads, void* stream) {
     JOVA_CHECK_ARG(params && grads && exp_avg && exp_inf && n >= 0 && step >= 1, "adamax_step: bad argument");
     if (n == 0) return JOVA_OK;
     const float bc = 1.f - powf(beta1, (float)step);
     hipLaunchKernelGGL(adamax_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_inf, (long long)n, lr, beta1, beta2, eps, weight_decay, grad_scale, bc);
+                       exp_inf, (long long)n, lr, beta1, beta2, eps, weight_decay, grad_scale, bc, skip_flag_or_null,
+                       zero_grads);
     JOVA_CHECK_LAUNCH("adamax_step");
     return JOVA_OK;
 }
@@ -384,6 +436,12 @@ extern "C" int jova_relu_bwd(const float* dy, const float* y, int64_t n, float* 
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, (long long)n, dx);
     JOVA_CHECK_LAUNCH("relu_bwd");
     return JOVA_OK;
+}
+
+extern "C" int jova_zero(float* p, int64_t n, void* stream) {
+    JOVA_CHECK_ARG(n >= 0 && (n == 0 || p), "zero: bad argument");
+    if (n == 0) return JOVA_OK;
+    return jova_zero_fill(p, (size_t)n * sizeof(float), 1, (size_t)n * sizeof(float), (hipStream_t)stream);
 }
 
 extern "C" int jova_axpy(const float* x, float a, int64_t n, float* y, void* stream) {

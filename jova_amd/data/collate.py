@@ -65,7 +65,8 @@ class MolTable(object):
 
     def select(self, ids):
         ids = np.asarray(ids, dtype=np.int64)
-        return np.ascontiguousarray(self.ptrs[ids].T), np.ascontiguousarray(self.n_atoms[ids]), int(self.n_edges[ids].sum())
+        return np.ascontiguousarray(self.ptrs[ids].T), np.ascontiguousarray(self.n_atoms[ids]), \
+            np.ascontiguousarray(self.n_edges[ids])
 
 
 def gconv_input_list(mols, device, stream=None, ids=None, extras=()):
@@ -78,15 +79,16 @@ def gconv_input_list(mols, device, stream=None, ids=None, extras=()):
     then ``extras``: further float32 / int32 arrays of the batch, returned as device views in ``glist.extras``).
     The per-batch topology (symmetry, host copy of deg_slice, molecule offsets, block order) rides along."""
     if isinstance(mols, MolTable):
-        ptrs, cnt, e = mols.select(ids)
+        ptrs, cnt, n_nbr = mols.select(ids)
         f = mols.n_feat
     else:
         hs = [_native_handles(m) for m in mols]
         ptrs = np.array([[h[3], h[4], h[5]] for h in hs], dtype=np.uint64).reshape(len(hs), 3).T.copy()
         cnt = np.array([h[6] for h in hs], dtype=np.int32)
-        e = int(sum(h[7] for h in hs))
+        n_nbr = np.array([h[7] for h in hs], dtype=np.int64)
         f = int(hs[0][0].shape[1]) if hs else 75
     n_mols = int(cnt.size)
+    e = int(n_nbr.sum())
     n = int(cnt.sum())
     n_atoms_lst = cnt.tolist()
     n_blocks = (n + 15) // 16
@@ -117,7 +119,7 @@ def gconv_input_list(mols, device, stream=None, ids=None, extras=()):
     if n_mols == 0:
         ptrs = np.zeros((3, 1), np.uint64)
     F_.call("jova_collate_gconv", n_mols, V(cnt.ctypes.data), V(ptrs[0].ctypes.data), V(ptrs[1].ctypes.data),
-            V(ptrs[2].ctypes.data), f, V(p_nodes), V(p_ds), V(p_memb), V(p_adj), V(p_off), V(p_order) if n_blocks else None,
+            V(ptrs[2].ctypes.data), V(n_nbr.ctypes.data), f, V(p_nodes), V(p_ds), V(p_memb), V(p_adj), V(p_off), V(p_order) if n_blocks else None,
             ctypes.byref(sym), V(p_adj + 4 * o_f32) if with_derived else None, ld,
             V(p_adj + 4 * o_rev) if with_derived else None)
     h32 = host[(n64 + pad64) * 8:].view(torch.int32).numpy()

@@ -176,7 +176,12 @@ class FlatParameters(object):
         self.params, self.n_params, self.numel = params, n, total
 
     def zero_grad(self):
-        self.grad.zero_()
+        """One fill kernel of the library over the flat buffer (Trainer.step does not need it: the optimizer kernels
+        clear the gradient once they have consumed it)."""
+        if self.grad.is_cuda:
+            _lib.call("jova_zero", _lib.P(self.grad), self.grad.numel(), _lib.stream())
+        else:                                   # host buffers: only the gloo rehearsal tests of the all-reduce get here
+            self.grad.zero_()
 
 
 class GradAllReduce(object):
@@ -190,21 +195,27 @@ class GradAllReduce(object):
     def __init__(self, process_group=None):
         self.pg = process_group
         self.backend = torch.distributed.get_backend(process_group)
-        self._host = None
-        self.host_staged = self.backend == "gloo" and not os.environ.get("JOVA_GLOO_DEVICE_TENSORS")
+        self._host = {}                          # pinned staging buffers, one per dtype
+        # gloo never sees a device tensor here: its device-tensor path hung inside the step on this image (DESIGN.md
+        # section 5), so the only gloo form is the host-staged one
+        self.host_staged = self.backend == "gloo"
 
     def supports_async(self, t):
         return not (self.host_staged and t.is_cuda)
 
     def __call__(self, t, async_op=False):
         if t.is_cuda and self.host_staged:
-            if self._host is None or self._host.numel() < t.numel():
-                self._host = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
-            h = self._host[:t.numel()]
-            h.copy_(t.reshape(-1), non_blocking=True)
+            if not t.is_contiguous():
+                raise ValueError("GradAllReduce: the tensor must be contiguous (a copy would receive the result)")
+            buf = self._host.get(t.dtype)
+            if buf is None or buf.numel() < t.numel():
+                buf = self._host[t.dtype] = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
+            h = buf[:t.numel()]
+            flat = t.view(-1)
+            h.copy_(flat, non_blocking=True)
             torch.cuda.current_stream().synchronize()
             torch.distributed.all_reduce(h, group=self.pg)
-            t.reshape(-1).copy_(h, non_blocking=True)
+            flat.copy_(h, non_blocking=True)
             return None
         return torch.distributed.all_reduce(t, group=self.pg, async_op=async_op)
 
@@ -274,8 +285,10 @@ _OPTIM_DEFAULTS = {
     "rmsprop": dict(lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0.0, momentum=0.0, centered=False),
     "adagrad": dict(lr=1e-2, lr_decay=0.0, weight_decay=0.0, initial_accumulator_value=0.0, eps=1e-10),
     "adadelta": dict(lr=1.0, rho=0.9, eps=1e-6, weight_decay=0.0),
+    "asgd": dict(lr=1e-2, lambd=1e-4, alpha=0.75, t0=1e6, weight_decay=0.0),
+    "rprop": dict(lr=1e-2, etas=(0.5, 1.2), step_sizes=(1e-6, 50.0)),
 }
-_OPTIM_KIND = {"adam": 2, "rmsprop": 3, "adagrad": 4, "adadelta": 5}
+_OPTIM_KIND = {"adam": 2, "rmsprop": 3, "adagrad": 4, "adadelta": 5, "asgd": 6, "rprop": 7}
 
 
 def optimizer_kwargs(hparams):
@@ -297,9 +310,6 @@ class FlatOptimizer(object):
     def __init__(self, flat, name, **kwargs):
         self.name = name.lower()
         if self.name not in _OPTIM_DEFAULTS:
-            if self.name in ("asgd", "rprop"):
-                raise NotImplementedError("optimizer %r is in the reference's table but has no flat-buffer kernel here "
-                                          "(sgd, adamax, adam, rmsprop, adagrad, adadelta do)" % name)
             raise AssertionError("%s optimizer could not be found" % name)
         self.opts = dict(_OPTIM_DEFAULTS[self.name])
         for k, v in kwargs.items():
@@ -313,6 +323,9 @@ class FlatOptimizer(object):
         self.lr = float(o["lr"])                        # current learning rate (a scheduler rewrites it)
         self.initial_lr = self.lr
         self.step_idx = 0
+        # device flag (jova_nonfinite_flag) that freezes parameters and state while set; grads cleared after use
+        self.skip_flag = None
+        self.zero_grads = False
         z = lambda: torch.zeros_like(flat.data)        # noqa: E731
         self.s1 = self.s2 = None
         if self.name == "sgd":
@@ -323,25 +336,43 @@ class FlatOptimizer(object):
             self.s1, self.s2 = z(), (z() if o["momentum"] else None)
         elif self.name == "adagrad":
             self.s1 = torch.full_like(flat.data, float(o["initial_accumulator_value"]))
+        elif self.name == "asgd":
+            self.s1 = z()                               # ax; eta and mu follow from the step count (kernel side)
+        elif self.name == "rprop":
+            self.s1, self.s2 = z(), torch.full_like(flat.data, self.lr)       # prev gradient, per-element step size
 
     def step(self, grad_scale=1.0):
         f, o = self.flat, self.opts
         self.step_idx += 1
         P_, st = _lib.P, _lib.stream()
-        wd = float(o["weight_decay"])
+        wd = float(o.get("weight_decay", 0.0))
+        tail = (P_(self.skip_flag), int(self.zero_grads), st)
         if self.name == "sgd":
             _lib.call("jova_sgd_step", P_(f.data), P_(f.grad), P_(self.s1), f.numel, self.lr, wd, float(o["momentum"]),
-                      grad_scale, int(self.step_idx == 1), st)
+                      grad_scale, int(self.step_idx == 1), *tail)
         elif self.name == "adamax":
             _lib.call("jova_adamax_step", P_(f.data), P_(f.grad), P_(self.s1), P_(self.s2), f.numel, self.lr,
-                      float(o["betas"][0]), float(o["betas"][1]), float(o["eps"]), wd, grad_scale, self.step_idx, st)
+                      float(o["betas"][0]), float(o["betas"][1]), float(o["eps"]), wd, grad_scale, self.step_idx, *tail)
         else:
-            h = {"adam": (o.get("betas", (0, 0))[0], o.get("betas", (0, 0))[1], o["eps"]),
-                 "rmsprop": (o.get("alpha", 0), o["eps"], o.get("momentum", 0)),
-                 "adagrad": (o.get("lr_decay", 0), o["eps"], 0.0),
-                 "adadelta": (o.get("rho", 0), o["eps"], 0.0)}[self.name]
+            if self.name == "adam":
+                h = (o["betas"][0], o["betas"][1], o["eps"], 0.0, 0.0)
+            elif self.name == "rmsprop":
+                h = (o["alpha"], o["eps"], o["momentum"], 0.0, 0.0)
+            elif self.name == "adagrad":
+                h = (o["lr_decay"], o["eps"], 0.0, 0.0, 0.0)
+            elif self.name == "adadelta":
+                h = (o["rho"], o["eps"], 0.0, 0.0, 0.0)
+            elif self.name == "asgd":
+                h = (o["lambd"], o["alpha"], o["t0"], 0.0, 0.0)
+            else:                                       # rprop
+                h = (o["etas"][0], o["etas"][1], 0.0, o["step_sizes"][0], o["step_sizes"][1])
+            lr = self.lr
+            if self.name == "asgd":
+                # torch keeps eta as state, computed at the END of a step from the learning rate of that step: step k
+                # runs with eta(lr of step k-1, k-1); the first step with eta = lr
+                lr, self._asgd_prev_lr = (getattr(self, "_asgd_prev_lr", None) or self.lr), self.lr
             _lib.call("jova_optim_step", _OPTIM_KIND[self.name], P_(f.data), P_(f.grad), P_(self.s1), P_(self.s2), f.numel,
-                      self.lr, wd, grad_scale, self.step_idx, float(h[0]), float(h[1]), float(h[2]), st)
+                      lr, wd, grad_scale, self.step_idx, *[float(v) for v in h], *tail)
 
 
 class StepLR(object):
@@ -387,6 +418,10 @@ class Trainer(object):
         self.optimizer = FlatOptimizer(self.flat, hp_opt["optimizer"], **optimizer_kwargs(hp_opt))
         self.scheduler = StepLR(self.optimizer, step_size=500, gamma=0.01)       # train_joint_attn.py:360
         self.nan_flag = torch.zeros(1, dtype=torch.int32, device=self.flat.data.device)
+        # a non-finite loss freezes the weights from that batch on (the reference leaves its loop before backward /
+        # optimizer.step, train_joint_attn.py:468-470); the gradient buffer is cleared by the optimizer kernel itself
+        self.optimizer.skip_flag = self.nan_flag
+        self.optimizer.zero_grads = True
         self.loss_sum = torch.zeros(1, dtype=torch.float32, device=self.flat.data.device)
         self.sync = None
         # (force_sync: run the collectives of the N-rank step on a one-rank group -- rehearsal on a one-GPU box)
@@ -428,8 +463,12 @@ class Trainer(object):
                 self.step(batch)
                 n_steps += 1
             self.check_health()
-            if int(self.nan_flag.item()):                          # one read per epoch
-                history.append(dict(epoch=epoch, terminated="non-finite loss"))
+            bad = int(self.nan_flag.item())                        # one read per epoch (bit 0 NaN, bit 1 infinity)
+            if bad:
+                # The optimizer kernels stopped updating at the offending batch, so the weights are the last finite
+                # ones -- what the reference returns when it breaks out at `str(loss.item()) == "nan"` (:468-470, :542).
+                # An infinite loss ends the run here too (the reference would run one more batch into the NaN).
+                history.append(dict(epoch=epoch, terminated="NaN loss" if bad & 1 else "infinite loss"))
                 break
             ep_loss = float(self.loss_sum.item()) / max(n_steps, 1)
             e_avg.update(ep_loss)
@@ -478,6 +517,7 @@ class Trainer(object):
                 buf.data.div_(self.world_size)
 
     def forward_loss(self, batch):
+        self._grads_clean = False               # a backward of this loss will write into the flat gradient buffer
         if self.sync is None:
             outputs = self.model(batch.model_input())
         else:                                   # same module sequence, with a watch on the encoders' outputs
@@ -489,7 +529,10 @@ class Trainer(object):
         return F_.MSELossFunction.apply(outputs, batch.w, batch.y), outputs
 
     def step(self, batch):
-        self.flat.zero_grad()
+        # optimizer.zero_grad() (train_joint_attn.py:428): the optimizer kernel of the previous step cleared the flat
+        # buffer after consuming it; a fill is only needed when something else ran a backward in between
+        if not getattr(self, "_grads_clean", False):
+            self.flat.zero_grad()
         loss, outputs = self.forward_loss(batch)
         loss.backward()
         scale = 1.0
@@ -504,4 +547,5 @@ class Trainer(object):
         _lib.call("jova_nonfinite_flag", _lib.P(lv), 1, _lib.P(self.nan_flag), _lib.stream())
         _lib.call("jova_axpy", _lib.P(lv), 1.0, 1, _lib.P(self.loss_sum), _lib.stream())
         self.optimizer.step(scale)
+        self._grads_clean = bool(self.optimizer.zero_grads)
         return loss, outputs

@@ -122,7 +122,8 @@ def test_shards_run_sequentially_equal_oracle_per_shard_averaged(device, world):
     # the optimizer applies the mean: grad_scale = 1 / world on the summed buffer (what Trainer.step does after all_reduce)
     lr, wd = HP["optimizer__global__lr"], HP["optimizer__global__weight_decay"]
     before = {k: v.detach().cpu().double().clone() for k, v in named.items()}
-    call("jova_sgd_step", P(tr.flat.data), P(tr.flat.grad), None, tr.flat.numel, lr, wd, 0.0, 1.0 / world, 1, stream())
+    call("jova_sgd_step", P(tr.flat.data), P(tr.flat.grad), None, tr.flat.numel, lr, wd, 0.0, 1.0 / world, 1, None, 0,
+         stream())
     for k, want in g64.items():
         after = named[k].detach().cpu().double()
         step_want = -lr * (want + wd * before[k])

@@ -25,8 +25,11 @@ def test_optimizer_kwargs_filter_and_table():
     assert o.opts["eps"] == 1e-6 and o.lr == 1e-3 and o.opts["betas"] == (0.9, 0.999)
     with pytest.raises(TypeError, match="unexpected keyword"):
         FlatOptimizer(Flat, "sgd", betas=(0.9, 0.99))
-    with pytest.raises(NotImplementedError):
-        FlatOptimizer(Flat, "Rprop")
+    r = FlatOptimizer(Flat, "Rprop", lr=0.02)                      # the whole table of :276-285 is there
+    assert r.opts["etas"] == (0.5, 1.2) and float(r.s2[0]) == pytest.approx(0.02)
+    with pytest.raises(TypeError, match="unexpected keyword"):     # torch.optim.Rprop takes no weight_decay either
+        FlatOptimizer(Flat, "rprop", weight_decay=0.01)
+    assert FlatOptimizer(Flat, "ASGD").opts["t0"] == 1e6
     with pytest.raises(AssertionError):
         FlatOptimizer(Flat, "lbfgs")
 
@@ -53,7 +56,9 @@ def test_step_lr_schedule():
     ("rmsprop", dict(lr=1e-3, alpha=0.9, weight_decay=0.001)), ("rmsprop", dict(lr=1e-3, momentum=0.7)),
     ("adagrad", dict(lr=1e-2, lr_decay=0.1, initial_accumulator_value=0.2, weight_decay=0.01)),
     ("adadelta", dict(rho=0.8, weight_decay=0.01)), ("adamax", dict(lr=4e-4, weight_decay=7e-4)),
-    ("sgd", dict(lr=4.7e-3, weight_decay=1.91e-2)), ("sgd", dict(lr=1e-2, momentum=0.9))])
+    ("sgd", dict(lr=4.7e-3, weight_decay=1.91e-2)), ("sgd", dict(lr=1e-2, momentum=0.9)),
+    ("asgd", dict(lr=1e-2, weight_decay=0.01)), ("asgd", dict(lr=5e-2, lambd=1e-2, alpha=0.6, t0=3)),
+    ("rprop", dict(lr=1e-2)), ("rprop", dict(lr=5e-3, etas=(0.4, 1.5), step_sizes=(1e-3, 2e-2)))])
 def test_flat_optimizers_and_step_lr_equal_torch_optim(device, name, kw):
     """Eight steps on a 5 000-element flat buffer with a fresh random gradient each step; StepLR(step_size=3, gamma=0.1)
     stepped after every step, so the learning rate changes twice inside the run."""
@@ -62,7 +67,8 @@ def test_flat_optimizers_and_step_lr_equal_torch_optim(device, name, kw):
     n = 5000
     p0 = torch.randn(n, generator=g)
     cls = {"adam": torch.optim.Adam, "rmsprop": torch.optim.RMSprop, "adagrad": torch.optim.Adagrad,
-           "adadelta": torch.optim.Adadelta, "adamax": torch.optim.Adamax, "sgd": torch.optim.SGD}[name]
+           "adadelta": torch.optim.Adadelta, "adamax": torch.optim.Adamax, "sgd": torch.optim.SGD,
+           "asgd": torch.optim.ASGD, "rprop": torch.optim.Rprop}[name]
     ref_p = torch.nn.Parameter(p0.double().clone())
     ref_opt = cls([ref_p], **kw)
     ref_sch = torch.optim.lr_scheduler.StepLR(ref_opt, step_size=3, gamma=0.1)
@@ -75,6 +81,10 @@ def test_flat_optimizers_and_step_lr_equal_torch_optim(device, name, kw):
     sch = StepLR(opt, step_size=3, gamma=0.1)
     for k in range(8):
         grad = torch.randn(n, generator=g)
+        if name == "rprop":
+            # Rprop reads only signs: repeat some signs, flip others, and put exact zeros in (all three branches); the
+            # gradient values are dyadic so that fp32 and the fp64 torch run see identical sign products
+            grad = torch.round(grad * 8) / 8
         ref_p.grad = grad.double() * 0.5
         ref_opt.step()
         ref_sch.step()
@@ -83,6 +93,10 @@ def test_flat_optimizers_and_step_lr_equal_torch_optim(device, name, kw):
         sch.step()
         assert abs(opt.lr - ref_opt.param_groups[0]["lr"]) <= 1e-12 * max(1.0, abs(opt.lr))
     H.assert_close(flat.data, ref_p.detach().float(), tol=2e-6, what=name)
+    if name == "asgd":                                             # the averaged iterate torch keeps as state['ax']
+        H.assert_close(opt.s1, ref_opt.state[ref_p]["ax"].float(), tol=2e-6, what="asgd ax")
+    if name == "rprop":
+        H.assert_close(opt.s2, ref_opt.state[ref_p]["step_size"].float(), tol=2e-6, what="rprop step sizes")
 
 
 @pytest.mark.gpu
@@ -94,10 +108,76 @@ def test_nonfinite_flag_and_fail_fast(device):
     assert int(flag.item()) == 0
     x[777] = float("inf")
     call("jova_nonfinite_flag", P(x), 1000, P(flag), stream())
-    assert int(flag.item()) == 1
+    assert int(flag.item()) == 2                                   # bit 1: an infinity
     x[777] = 0.0
     call("jova_nonfinite_flag", P(x), 1000, P(flag), stream())
-    assert int(flag.item()) == 1                                   # sticky until the host clears it
+    assert int(flag.item()) == 2                                   # sticky until the host clears it
+    x[3] = float("nan")
+    call("jova_nonfinite_flag", P(x), 1000, P(flag), stream())
+    assert int(flag.item()) == 3                                   # bit 0: a NaN (what the reference tests for)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["sgd", "adamax", "adam", "asgd", "rprop"])
+def test_optimizer_kernels_freeze_on_the_flag_and_clear_consumed_gradients(device, name):
+    """skip_flag set: parameters and optimizer state stay bit-identical (the reference never reaches optimizer.step on a
+    NaN batch, train_joint_attn.py:468-486); zero_grads: the gradient buffer is cleared either way."""
+    from jova_amd.train import FlatOptimizer
+
+    class Flat:
+        pass
+    flat = Flat()
+    n = 3000
+    flat.data, flat.grad, flat.numel = torch.randn(n, device=device), torch.randn(n, device=device), n
+    opt = FlatOptimizer(flat, name)
+    opt.skip_flag = torch.zeros(1, dtype=torch.int32, device=device)
+    opt.zero_grads = True
+    opt.step()
+    assert float(flat.grad.abs().max()) == 0.0
+    after1 = flat.data.clone()
+    st = [None if t is None else t.clone() for t in (opt.s1, opt.s2)]
+    flat.grad.copy_(torch.full((n,), float("nan"), device=device))
+    opt.skip_flag.fill_(1)
+    opt.step()
+    assert torch.equal(flat.data, after1) and float(flat.grad.abs().max()) == 0.0
+    for a, b in zip(st, (opt.s1, opt.s2)):
+        assert a is None or torch.equal(a, b)
+    opt.skip_flag.zero_()
+    flat.grad.copy_(torch.randn(n, device=device))
+    opt.step()
+    assert not torch.equal(flat.data, after1) and torch.isfinite(flat.data).all()
+
+
+@pytest.mark.gpu
+def test_nan_loss_in_epoch_zero_returns_the_last_finite_weights(device):
+    """a NaN in epoch 0 (no best epoch yet).  The reference breaks out before backward / optimizer.step and
+    hands back the model as it stands, i.e. the weights after the last finite batch (train_joint_attn.py:468-470, :351,
+    :542).  Here: batch 0 is clean, batch 1 carries a NaN label, batch 2 is clean again -- the weights must equal the
+    weights after batch 0 alone, bit for bit, and fit() must report the termination."""
+    import __graft_entry__  # noqa: F401  (repo root on sys.path)
+    from test_gpu_ops import _e2e_setup
+    from jova_amd.data.collate import DtiBatch
+    from jova_amd.train import Trainer
+    z, hp, hparams, net, batch = _e2e_setup(device)
+    hparams = dict(hparams, dprob=0.0)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    tr = Trainer(net, hparams)
+    w0 = tr.flat.data.clone()
+    tr.step(batch)
+    torch.cuda.synchronize()
+    want = tr.flat.data.clone()
+    moved = float((want - w0).abs().max())
+    assert moved > 0
+    net.load_state_dict(sd0)
+    tr2 = Trainer(net, hparams)
+    bad_y = batch.y.clone()
+    bad_y.view(-1)[0] = float("nan")
+    bad = DtiBatch(batch.ecfp, batch.glist, batch.prot_names, bad_y, batch.w, batch.prot_input, batch.psc)
+    res = tr2.fit(lambda ep: [batch, bad, batch], None, n_epochs=3)
+    assert res["epoch"] == -1 and res["history"][-1]["terminated"] == "NaN loss" and len(res["history"]) == 1
+    assert torch.isfinite(tr2.flat.data).all()
+    # (split-K float atomics order the sums of a step differently from run to run: equal to a small fraction of one update)
+    assert float((tr2.flat.data - want).abs().max()) <= 1e-3 * moved, "weights moved after the NaN batch"
 
 
 @pytest.mark.gpu
