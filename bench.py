@@ -83,6 +83,35 @@ def build_batches(pool, conv_mols, hp, device, n_batches, prot2vec, shape, world
     return out, sampler, make_batch
 
 
+def step_flops(hp, batch):
+    """Algorithmic FLOPs (2 per multiply-add) of one training step on `batch` and its token count S * B.
+
+    Forward products only are enumerated; backward = 2 x forward (one data and one weight gradient per product; the few
+    input gradients the step does not need -- fingerprints, descriptors -- are counted all the same: < 0.1 %).  Padded
+    tokens count: the reference's attention has no padding mask (models.py:952), they are real work.
+      JointAttention (models.py:939-973), T = S B tokens: view projections 2 B L sum_v n_v d_v, QKV 6 T L^2, scores and PV
+      4 B S^2 L, out-proj 2 T L^2, FFN 4 T L I;  ProteinCNN2D (:760-771) 2 P_max B (layers-1) (11e)^2 + 2 P_max B 11e e;
+      GraphConv x2 4 N F_in F_out (layers.py:312-339) + Linear 2 N 64 g;  FC head 2 B sum p_in p_out."""
+    B = batch.batch_size
+    L, I = hp["latent_dim"], 2048
+    g, e, win = hp["gconv"]["dim"], hp["prot"]["embedding_dim"], hp["prot"]["window"]
+    n_atoms = batch.glist[0].shape[0]
+    a_max = max(batch.glist[3])
+    p_max = int(batch.prot_input[2])
+    views = [(1, hp["ecfp8"]["dim"]), (a_max, g), (p_max, e)] + ([(1, hp["prot"]["psc_dim"])] if batch.psc is not None else [])
+    S = sum(n for n, _ in views)
+    T = S * B
+    ja = 2.0 * B * L * sum(n * d for n, d in views) + hp["attn_layers"] * (8.0 * T * L * L + 4.0 * T * L * I + 4.0 * B * S * S * L)
+    d = win * e
+    pcnn = 2.0 * p_max * B * ((hp["prot"]["pcnn_num_layers"] - 1) * d * d + d * e)
+    gconv = 4.0 * n_atoms * (75 * 64 + 64 * 64) + 2.0 * n_atoms * 64 * g
+    head, p_in = 0.0, len(views) * L
+    for p_out in list(hp["lin_dims"]) + [hp["output_dim"]]:
+        head += 2.0 * B * p_in * p_out
+        p_in = p_out
+    return 3.0 * (ja + pcnn + gconv + head), T
+
+
 def launch_ranks(n):
     """``python bench.py --gpus N`` from a bare shell: this parent never touches the GPU; it starts N rank processes
     (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1) that run this same file, and exits with their code.
@@ -468,6 +497,11 @@ def main():
                     overlapped=trainer.sync is not None)
 
     bsz = hp["tr_batch_size"]
+    # work of the timed steps, so that pairs/s can be compared across batch sets and rounds
+    per_batch = [step_flops(hp, b) for b in batches]
+    timed = [per_batch[i % len(batches)] for i in range(args.steps)]
+    flops_per_step = float(np.mean([f for f, _ in timed]))
+    tokens_per_step = float(np.mean([t for _, t in timed]))
     pairs_per_s = args.steps * bsz * world / elapsed
     # dominant kernel: the fp32 MFMA GEMM; probe = the FFN linear1 launch (largest single launch of the step)
     flops = sum(f for _, _, f in probe)
@@ -476,8 +510,10 @@ def main():
     roofline = dict(kernel="gemm_f32_fast_kernel<K-contig,K-contig> (JointAttention FFN linear1, [S*B,512]x[512,2048]+bias+ReLU)",
                     bound="mfma", achieved=round(tfl, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(tfl / MFMA_F32_PEAK_TFLOPS, 4), traffic=measured_traffic(),
-                    traffic_note="bytes per launch at S=279 (profiles/r02_pmc_ffn1.json: 2*FETCH_SIZE + WRITE_SIZE, "
-                                 "separate --pmc passes); algorithmic bytes of that launch 369.9e6",
+                    traffic_note="NOT re-measured in this run: bytes per launch of the S=279 launch that "
+                                 "profiles/r02_pmc_ffn1.json profiled (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes; "
+                                 "algorithmic bytes of that launch 369.9e6); this run's launches average S*B = %d tokens"
+                                 % int(tokens_per_step),
                     launches=len(probe), avg_us=round(ms * 1e3 / max(len(probe), 1), 1))
     line = dict(metric="DTI training pairs/sec (fwd+bwd, whole node) + achieved HBM GB/s fraction",
                 value=round(pairs_per_s, 1), unit="pairs/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -490,8 +526,19 @@ def main():
                 final_loss=round(final_loss, 6), roofline=roofline)
     line["config"]["sampler"] = ("ShardSampler: %d-pair synthetic epoch, %d disjoint shards, %d steps/epoch, tail dropped"
                                  % (sampler.n_pairs, world, sampler.steps_per_epoch))
+    line["work"] = dict(
+        tokens_per_step=round(tokens_per_step, 1), flops_per_step=round(flops_per_step, 0),
+        tflops_per_gpu=round(flops_per_step / (elapsed / args.steps) / 1e12, 2),
+        frac_of_fp32_matrix_peak=round(flops_per_step / (elapsed / args.steps) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+        note="per GPU, mean over the timed steps; tokens = S*B with S = 1 + A_max + P_max (+1 with the psc view), padded "
+             "tokens included (no padding mask in the reference); flops = algorithmic, 2 per multiply-add, backward = 2 x "
+             "forward (bench.py:step_flops); tflops_per_gpu = flops_per_step / ms_per_step -- with the backward products "
+             "on the bf16 pipe this is an fp32-EQUIVALENT rate, the fp32-pipe figure is fp32_mfma_only.tflops_per_gpu")
     line["fp32_mfma_only"] = dict(value=round(args.steps * bsz * world / elapsed_f, 1), unit="pairs/s",
-                                  ms_per_step=round(elapsed_f / args.steps * 1e3, 3))
+                                  ms_per_step=round(elapsed_f / args.steps * 1e3, 3),
+                                  tflops_per_gpu=round(flops_per_step / (elapsed_f / args.steps) / 1e12, 2),
+                                  frac_of_fp32_matrix_peak=round(flops_per_step / (elapsed_f / args.steps) / 1e12 /
+                                                                 MFMA_F32_PEAK_TFLOPS, 4))
     line["with_collation"] = dict(
         value=round(args.steps * bsz * world / elapsed_c, 1), unit="pairs/s", ms_per_step=round(elapsed_c / args.steps * 1e3, 3),
         ratio_to_resident=round(elapsed / elapsed_c, 4),

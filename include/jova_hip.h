@@ -295,9 +295,19 @@ int jova_gauss_hist_bwd(const float* x, const float* dout, int64_t n, float eps,
  * (NormalizationTransformer.untransform).  out6 = { rms, concordance index, pearson r^2, nanmean([ci, r2]) - rms,
  * swapped pairs (ties in the prediction count 0.5), pairs with different labels }; a quantity the reference cannot
  * form (no pair with different labels, constant input, no sample) is NaN.  ws16 = 128 bytes of device scratch.
- * Pair counts are exact integers; n <= 2^20. */
+ * Pair counts are exact integers; n <= 2^18 (the count is brute force, n^2 / 2 comparisons). */
 int jova_dti_metrics(const float* y_true, const float* y_pred, const float* w_or_null, int n, double y_std,
                      double y_mean, double* ws16, double* out6, void* stream);
+/* Multi-task form (output_dim = len(tasks) > 1, proj/dti/train_joint_attn.py:1027; "full ToxCast"): y_true / y_pred / w are
+ * [n, n_tasks] row-major.  Every task is measured as above on its own samples with w != 0, then the tasks are combined
+ * as Metric.compute_metric does with its default arithmetic_mean = True and task_averager = np.nanmean
+ * (jova/metrics/all_metrics.py:147, :517-600; jova/metrics/evaluate.py:17): sum over tasks with a finite value of
+ * n_t * value_t / N, with n_t the kept samples of task t and N their sum over the tasks the metric does not exclude (the
+ * concordance index excludes a task whose kept labels are all equal, :273-279).  out6 as above (swapped pairs and pairs
+ * summed over the tasks); per_task (optional) receives [n_tasks, 6] = rms, ci, r2, n_t, swapped, pairs per task.
+ * ws = 128 * n_tasks bytes of device scratch. */
+int jova_dti_metrics_tasks(const float* y_true, const float* y_pred, const float* w_or_null, int n, int n_tasks,
+                           double y_std, double y_mean, double* ws, double* per_task_or_null, double* out6, void* stream);
 
 /* ---- element-wise helpers (nn.ReLU and gradient bookkeeping) --------------------------------------------------- */
 int jova_relu_fwd(const float* x, int64_t n, float* y, void* stream);

@@ -47,6 +47,7 @@ _SIGS = {
     "jova_optim_step": "ipppp" + "qfffi" + "fffff" + "pip",
     "jova_nonfinite_flag": "pqpp",
     "jova_dti_metrics": "pppi" + "dd" + "ppp",
+    "jova_dti_metrics_tasks": "pppii" + "dd" + "pppp",
     "jova_copy2d": "pqiqpqiqip", "jova_linear_bwd_weight": "pqpqqiippip",
     "jova_gather_rows": "ppqiqpp", "jova_scatter_add_rows": "ppqiqpp", "jova_gauss_hist_fwd": "pqfpp",
     "jova_gauss_hist_bwd": "ppqfpp",

@@ -13,13 +13,31 @@ from . import _lib
 COLUMNS = ("nanmean-rms_score", "nanmean-concordance_index", "nanmean-pearson_r2_score", "score")
 
 
-def dti_metrics(outputs, y, w=None, y_std=1.0, y_mean=0.0, out=None, ws=None):
+def dti_metrics(outputs, y, w=None, y_std=1.0, y_mean=0.0, out=None, ws=None, per_task=None):
     """-> float64 device tensor [rms, ci, r2, score, swapped_pairs, pairs] of one batch (no host synchronisation).
 
     outputs / y / w: device tensors of n elements (any shape; fp32).  w == 0 drops a sample (all_metrics.py:651-652);
     y_std / y_mean undo the label z-scoring of NormalizationTransformer before the metrics are taken, as
-    compute_model_performance does with ``transformers``."""
+    compute_model_performance does with ``transformers``.
+
+    Multi-task models (``output_dim = len(tasks) > 1``, train_joint_attn.py:1027): ``y`` of shape [n, T] with T > 1 selects
+    the per-task form -- every task measured on its own samples with w != 0, the tasks then combined the way
+    Metric.compute_metric does (observation-weighted nan-mean, all_metrics.py:517-600); ``per_task`` (optional float64
+    device tensor [T, 6]) receives rms, ci, r2, n_t, swapped, pairs of every task."""
     _lib.require_gpu(outputs, y, w)
+    if y.dim() == 2 and y.shape[1] > 1:
+        n, T = y.shape
+        p2 = outputs.detach().reshape(n, T).float().contiguous()
+        t2 = y.detach().float().contiguous()
+        w2 = None if w is None else w.detach().reshape(n, T).float().contiguous()
+        if out is None:
+            out = torch.empty(6, dtype=torch.float64, device=p2.device)
+        if ws is None or ws.numel() < 16 * T:
+            ws = torch.empty(16 * T, dtype=torch.float64, device=p2.device)
+        assert per_task is None or (per_task.dtype == torch.float64 and per_task.numel() >= 6 * T and per_task.is_contiguous())
+        _lib.call("jova_dti_metrics_tasks", _lib.P(t2), _lib.P(p2), _lib.P(w2), int(n), int(T), float(y_std), float(y_mean),
+                  _lib.P(ws), _lib.P(per_task), _lib.P(out), _lib.stream())
+        return out
     p = outputs.detach().reshape(-1).float().contiguous()
     t = y.detach().reshape(-1).float().contiguous()
     if p.numel() != t.numel():

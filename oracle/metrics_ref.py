@@ -82,3 +82,43 @@ def dti_metrics(y, p, w=None, y_std=1.0, y_mean=0.0):
     y, p = y * y_std + y_mean, p * y_std + y_mean
     rms, ci, r2 = rms_score(y, p), concordance_index(y, p), pearson_r2_score(y, p)
     return rms, ci, r2, float(np.nanmean([ci, r2]) - rms)
+
+
+def dti_metrics_multitask(y, p, w=None, y_std=1.0, y_mean=0.0):
+    """[n, T] labels / predictions / weights -> (rms, ci, r2, score): every task measured on its samples with w != 0, then
+    combined as Metric.compute_metric does with the constructor default arithmetic_mean=True and task_averager=np.nanmean
+    (all_metrics.py:147, :256-296, :517-600; the driver's Metric(fn, np.nanmean), train_joint_attn.py:299-301):
+        task value   = NaN without samples; for the concordance index also NaN -- and the task EXCLUDED -- when all kept
+                       labels are equal (:271-279)
+        coefficient  = included_tasks * n_t / N,  N = sum of n_t over the tasks that are not excluded (:560-581)
+        result       = np.nanmean(coefficient * value) = sum over finite values of n_t * value_t / N
+    Pinned by tools/make_golden_metrics.py against the reference's own Metric class (metrics_multitask.npz)."""
+    y, p = np.asarray(y, np.float64), np.asarray(p, np.float64)
+    n, T = y.shape
+    w = np.ones_like(y) if w is None else np.asarray(w, np.float64).reshape(n, T)
+    y, p = y * y_std + y_mean, p * y_std + y_mean
+    res = []
+    for fn, excludes_constant_labels in ((rms_score, False), (concordance_index, True), (pearson_r2_score, False)):
+        vals, nobs, total = [], [], 0
+        for t in range(T):
+            keep = w[:, t] != 0
+            n_t = int(keep.sum())
+            if n_t == 0:
+                vals.append(np.nan)
+                nobs.append(0)
+                continue
+            yt, pt = y[keep, t], p[keep, t]
+            if excludes_constant_labels and not (yt != yt[0]).any():
+                vals.append(np.nan)                 # excluded: its samples leave N as well
+                nobs.append(0)
+                continue
+            with np.errstate(all="ignore"):
+                vals.append(fn(yt, pt))
+            nobs.append(n_t)
+            total += n_t
+        vals, nobs = np.array(vals), np.array(nobs, np.float64)
+        ok = ~np.isnan(vals)
+        res.append(float((vals[ok] * nobs[ok]).sum() / total) if ok.any() and total > 0 else float("nan"))
+    rms, ci, r2 = res
+    return rms, ci, r2, float(np.nanmean([ci, r2]) - rms)
+

@@ -81,7 +81,7 @@ def assert_close(a, b, tol=1e-5, what="", floor=0.0):
 
 
 # ---------------------------------------------------------------------------------------------- full-size fixtures
-FULL_TAGS = ("davis_b128", "kiba_b128", "metz_psc_b128", "davis_b256_default", "long1024_b128")
+FULL_TAGS = ("davis_b128", "kiba_b128", "metz_psc_b128", "davis_b256_default", "long1024_b128", "metz_psc_t12_b128")
 
 
 def full_setup(tag):
@@ -91,7 +91,8 @@ def full_setup(tag):
     z = load("full_" + tag)
     spec = json.loads(str(z["spec"]))
     hp = spec["hp"]
-    hparams = {"attn_heads": hp["heads"], "attn_layers": hp["attn_layers"], "lin_dims": hp["lin_dims"], "output_dim": 1,
+    hparams = {"attn_heads": hp["heads"], "attn_layers": hp["attn_layers"], "lin_dims": hp["lin_dims"],
+               "output_dim": hp.get("out_dim", 1),
                "latent_dim": hp["latent"], "dprob": hp["dprob"], "optimizer": "sgd", "tr_batch_size": spec["batch"],
                "optimizer__global__lr": 4.70e-3, "optimizer__global__weight_decay": 1.91e-2,
                "prot": {"model_types": list(spec["views"]), "vocab_size": hp["vocab"], "window": hp["window"],
@@ -101,7 +102,20 @@ def full_setup(tag):
     mi, pi, y, w = pool.sample_pairs(np.random.RandomState(spec["pair_seed"]), spec["batch"])
     if spec["shape"] == "long1024":
         pi[0] = 0
+    T = hp.get("out_dim", 1)
+    if T > 1:                                   # multi-task labels / weights (tools/make_golden_full.py:task_labels)
+        r = np.random.RandomState(spec["pair_seed"] + 7919)
+        y = r.normal(size=(y.shape[0], T))
+        w = (r.uniform(size=y.shape) >= hp["missing"]).astype(np.float64)
+        y = y * w
     return z, spec, hparams, pool, mi, pi, y, w
+
+
+def proj_vectors(name, numel, k=8):
+    """The seeded +-1 vectors of tools/make_golden_full.py:proj_vectors (whole-tensor projections gp64.<name>)."""
+    import zlib
+    r = np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    return r.randint(0, 2, size=(k, numel)).astype(np.float64) * 2.0 - 1.0
 
 
 def full_net(spec, hparams, pool):
@@ -125,6 +139,18 @@ def sample_index(numel, k=2048):
     return np.unique(np.linspace(0, numel - 1, min(numel, k)).astype(np.int64))
 
 
+def flip_scale(z):
+    """What ONE flipped ReLU mask does to the largest element of a parameter-gradient tensor, as the reference's own fp32
+    runs show it: the largest max|g32 - g64| / max|g64| over all tensors of the fixture (analytically-zero tensors aside).
+    Which tensor a flip lands in is decided by which pre-activation happens to sit within rounding of zero and differs
+    between any two fp32 executions (the reference's own three runs disagree about it), so the largest-element bounds use
+    this fixture-wide figure; the per-tensor L2 bounds do not need it.  Measured: on the multi-task fixture the reference's
+    fp32 runs flip masks of the first head layer (3.bias 1.0e-1, 2.weight 9.5e-2), the HIP step one mask of the second
+    (row 518 of 6.weight 9.9e-2, 7.bias[518] 3.0e-2, everything else of those tensors <= 2e-5), the fp32 oracle none."""
+    gmax = max(float(z[k][1]) for k in z.files if k.startswith("gstat."))
+    return max(float(z[k][2] / z[k][1]) for k in z.files if k.startswith("gstat.") and z[k][1] >= 1e-9 * gmax)
+
+
 def check_full_grads(z, grads, what):
     """grads: name -> float64 numpy gradient of the path under test.  Bound per tensor, derived from the reference's own
     fp32 run: err(test, ref64) <= max(1e-5, 2 * err(ref32, ref64)), err = max|difference| / max|ref64| over the tensor
@@ -137,6 +163,7 @@ def check_full_grads(z, grads, what):
     gmax = max(float(z[k][1]) for k in z.files if k.startswith("gstat."))
     stats = [z[k] for k in z.files if k.startswith("gstat.")]
     e_all = float(np.sqrt(sum(float(s[3]) ** 2 for s in stats) / sum(float(s[0]) ** 2 for s in stats)))
+    flip = flip_scale(z)
     worst = (0.0, "")
     for k in z.files:
         if not k.startswith("gstat."):
@@ -148,7 +175,7 @@ def check_full_grads(z, grads, what):
             assert float(np.abs(g).max()) <= max(1e-5 * gmax, 2 * dmax), "%s %s: analytically zero gradient is %.3e" % (
                 what, name, float(np.abs(g).max()))
             continue
-        bound = max(1e-5, 2 * max(dmax / mx, e_all))
+        bound = max(1e-5, 2 * max(dmax / mx, e_all, flip if g.size > 1 else 0.0))
         e = float(np.abs(g[sample_index(g.size)] - z["gs64." + name]).max()) / mx
         assert e <= bound, "%s %s: gradient sample err %.3e > %.3e (= max(1e-5, 2 x ref32-vs-ref64))" % (what, name, e, bound)
         bound2 = max(1e-5, 2 * max(dl2 / l2, e_all))
@@ -156,3 +183,68 @@ def check_full_grads(z, grads, what):
         assert e2 <= bound2, "%s %s: gradient L2 norm off by %.3e > %.3e" % (what, name, e2, bound2)
         worst = max(worst, (e / bound, name))
     return worst
+
+
+def check_oracle_projections(z, grads, what):
+    """Whole-tensor pin of an fp64 gradient set to the reference's double run: the 8 seeded +-1 projections of every
+    parameter gradient (gp64.<name>, tools/make_golden_full.py) agree to 1e-8 of the tensor's L2 norm.  A single wrong
+    element of size e moves every projection by e, so this holds EVERY element, not a sample."""
+    gmax = max(float(z[k][1]) for k in z.files if k.startswith("gstat."))
+    n = 0
+    for k in z.files:
+        if not k.startswith("gp64."):
+            continue
+        name = k[len("gp64."):]
+        g = np.asarray(grads[name], dtype=np.float64).reshape(-1)
+        got = proj_vectors(name, g.size) @ g
+        l2 = float(z["gstat." + name][0])
+        tol = 1e-8 * l2 + 1e-12 * gmax * np.sqrt(g.size)
+        assert float(np.abs(got - z[k]).max()) <= tol, "%s %s: projections of the oracle gradient off by %.3e (tol %.3e)" % (
+            what, name, float(np.abs(got - z[k]).max()), tol)
+        n += 1
+    assert n > 0, "fixture %s holds no whole-tensor projections" % what
+    return n
+
+
+def check_full_grads_whole(z, grads, ref64, what, fp32_oracle=None):
+    """Every ELEMENT of every parameter gradient: grads (path under test) against ref64, the fp64
+    oracle's gradients that check_oracle_projections has tied to the reference's double run.
+
+    Whole-tensor L2 distance: ||test - ref64|| / ||ref64|| <= max(1e-5, 2 * the reference's own fp32-vs-double L2 distance)
+    -- from the fixture alone, per tensor.  Largest single element: max|test - ref64| / max|ref64| <= max(1e-5, 2 * the
+    largest such distance among the fp32 executions on record): the reference's three fp32 runs (fixture; per tensor and
+    the fixture-wide flip_scale) and, when given, the fp32 oracle run on this machine (``fp32_oracle``: the same
+    restatement that the projections pin in double, evaluated in fp32).  Why the second source: the largest element over
+    10^5 - 10^6 entries is an extreme value decided by WHICH borderline ReLU pre-activations flip, and that differs between any two fp32 implementations -- measured on the Davis
+    fixture, 39 of the 199 078 embedding-gradient elements sit up to 5.4e-2 from the double run in the HIP step AND, the
+    same 39 elements by the same amounts, in the fp32 oracle, while the reference's own fp32 runs (other flips) reach
+    9.7e-3 there; on every other tensor the HIP step's largest deviation equals the reference's fp32 run's to three digits
+    (tools/dbg_whole_grad.py prints the table)."""
+    gmax = max(float(z[k][1]) for k in z.files if k.startswith("gstat."))
+    stats = [z[k] for k in z.files if k.startswith("gstat.")]
+    e_all = float(np.sqrt(sum(float(s[3]) ** 2 for s in stats) / sum(float(s[0]) ** 2 for s in stats)))
+    worst = (0.0, "")
+    for k in z.files:
+        if not k.startswith("gstat."):
+            continue
+        name = k[len("gstat."):]
+        l2, mx, dmax, dl2 = (float(v) for v in z[k])
+        g = np.asarray(grads[name], dtype=np.float64).reshape(-1)
+        r = np.asarray(ref64[name], dtype=np.float64).reshape(-1)
+        assert g.shape == r.shape, name
+        if mx < 1e-9 * gmax:
+            continue                                   # analytically zero: judged absolutely in check_full_grads
+        d = np.abs(g - r)
+        e32 = max(dmax / mx, flip_scale(z) if g.size > 1 else 0.0)
+        if fp32_oracle is not None:
+            e32 = max(e32, float(np.abs(np.asarray(fp32_oracle[name], dtype=np.float64).reshape(-1) - r).max()) / mx)
+        bound = max(1e-5, 2 * max(e32, e_all))
+        e = float(d.max()) / mx
+        assert e <= bound, "%s %s: whole-tensor gradient err %.3e > %.3e at element %d of %d" % (
+            what, name, e, bound, int(d.argmax()), g.size)
+        bound2 = max(1e-5, 2 * max(dl2 / l2, e_all))
+        e2 = float(np.sqrt((d ** 2).sum())) / l2
+        assert e2 <= bound2, "%s %s: whole-tensor L2 distance %.3e > %.3e" % (what, name, e2, bound2)
+        worst = max(worst, (e / bound, name))
+    return worst
+

@@ -1,6 +1,7 @@
 """Full-size parity against fixtures made by the imported reference (tools/make_golden_full.py): the tuned Davis model
-at B = 128, KIBA- and Metz+PSC-shaped batches, the default-hparams model at B = 256 and a long-protein stress batch
-(P_max = 1024, S = 1065 tokens), each run by the reference in fp32 AND in double.
+at B = 128, KIBA- and Metz+PSC-shaped batches, the default-hparams model at B = 256, a long-protein stress batch
+(P_max = 1024, S = 1065 tokens) and the multi-task variant of config 5 (output_dim = 12 tasks, 70 % of the labels
+missing: "full ToxCast"-shaped), each run by the reference in fp32 AND in double.
 
 Bound per tensor: err(x, ref64) <= max(1e-5, 2 * err(ref32, ref64)).  What the fixtures show: at these
 sizes the reference's own fp32 run sits 0.7 - 5e-5 from its double run on the outputs, and on the parameter gradients
@@ -48,10 +49,11 @@ def _oracle_run(tag, dtype=torch.float64):
     return z, out.detach().double().numpy(), float(loss), n_eval, grads
 
 
-@pytest.mark.parametrize("tag", ["davis_b128", "metz_psc_b128"])
+@pytest.mark.parametrize("tag", ["davis_b128", "metz_psc_b128", "metz_psc_t12_b128"])
 def test_oracle_fp64_equals_reference_double_run_at_full_size(tag):
     torch.set_num_threads(8)
     z, out, loss, n_eval, grads = _oracle_run(tag)
+    H.check_oracle_projections(z, grads, tag)                        # every element of every gradient tensor
     assert n_eval == int(z["nonsat_evals"][1]) == int(z["nonsat_evals"][0])
     assert H.rel_err(out, z["out64"]) <= 1e-9
     assert abs(loss - float(z["loss64"])) <= 1e-10 * abs(float(z["loss64"]))
@@ -137,3 +139,22 @@ def test_hip_step_vs_reference_full_size(device, tag):
     emb = "0.models.2.0.embedding.weight"
     assert float(np.abs(grads[emb][spec["hp"]["vocab"]]).max()) == 0.0         # the padding row receives nothing
     H.check_full_grads(z, grads, tag)
+    # whole tensors, not the 2 048-element sample: against the fp64 oracle run on this box's host cores, which the
+    # fixture's whole-tensor projections tie to the reference's double run element by element
+    torch.set_num_threads(min(16, torch.get_num_threads()) or 1)
+    _, out64, loss64, _, g64 = _oracle_run(tag)
+    assert H.rel_err(out64, z["out64"]) <= 1e-9
+    H.check_oracle_projections(z, g64, tag)
+    g32 = _oracle_run(tag, torch.float32)[4]
+    H.check_full_grads_whole(z, grads, g64, tag, fp32_oracle=g32)
+    if spec["hp"].get("out_dim", 1) > 1:
+        # the evaluation metrics of a multi-task batch: per task on its labelled samples, observation-weighted nan-mean
+        # (jova/metrics/evaluate.py:17 -> all_metrics.py:517-600), on the device, against the oracle on the same outputs
+        from jova_amd.metrics import MetricsLog
+        from oracle import metrics_ref as MR
+        log = MetricsLog(device)
+        score = log(out.detach() * batch.w, batch)
+        want = MR.dti_metrics_multitask(y.astype(np.float32), (out.detach() * batch.w).cpu().numpy(), w)
+        got = log.rows()[0, :4].cpu().numpy()
+        assert np.allclose(got, want, rtol=1e-10, atol=1e-12), (got, want)
+        assert abs(float(score) - want[3]) <= 1e-10

@@ -52,6 +52,57 @@ def test_oracle_degenerate_inputs():
     assert ci == 0.0 and abs(r2 - 1.0) < 1e-15
 
 
+MULTI = os.path.join(os.path.dirname(__file__), "golden", "metrics_multitask.npz")
+
+
+def _multi_cases():
+    z = np.load(MULTI)
+    for c in z["cases"]:
+        c = str(c)
+        yield c, z[c + ".y"], z[c + ".p"], z[c + ".w"], z[c + ".scale"], z[c + ".want"]
+
+
+def test_oracle_multitask_equals_reference_metric_class():
+    """metrics_multitask.npz holds what the reference's Metric.compute_metric returned (tools/make_golden_metrics_multitask.py):
+    12- and 17-task batches with 70 - 90 % of the labels missing (w = 0), a task without samples, a task whose kept labels
+    are all equal (excluded from the concordance index), and the single-task limit."""
+    n = 0
+    for c, y, p, w, sc, want in _multi_cases():
+        assert _close(MR.dti_metrics_multitask(y, p, w, sc[0], sc[1]), want, 1e-10), c
+        if y.shape[1] == 1:                                                   # T = 1: the single-task function agrees
+            assert _close(MR.dti_metrics(y, p, w, sc[0], sc[1]), want, 1e-10), c
+        n += 1
+    assert n == 6
+
+
+@pytest.mark.gpu
+def test_device_multitask_metrics_equal_reference_metric_class(device):
+    """jova_dti_metrics_tasks on [n, T] batches against the reference-made values; per-task rows against the oracle."""
+    from jova_amd.metrics import dti_metrics
+    for c, y, p, w, sc, want in _multi_cases():
+        n, T = y.shape
+        per_task = torch.full((T, 6), float("nan"), dtype=torch.float64, device=device)
+        if T == 1:                                                            # [n, 1] takes the single-task entry point
+            got = dti_metrics(torch.from_numpy(p).to(device), torch.from_numpy(y).to(device), torch.from_numpy(w).to(device),
+                              sc[0], sc[1]).cpu().numpy()
+            assert _close(got[:4], want), (c, got, want)
+            continue
+        got = dti_metrics(torch.from_numpy(p).to(device), torch.from_numpy(y).to(device), torch.from_numpy(w).to(device),
+                          sc[0], sc[1], per_task=per_task).cpu().numpy()
+        assert _close(got[:4], want), (c, got, want)
+        rows = per_task.cpu().numpy()
+        for t in range(T):
+            keep = w[:, t] != 0
+            assert rows[t, 3] == keep.sum()
+            if keep.sum() == 0:
+                assert np.isnan(rows[t, :3]).all()
+                continue
+            yt, pt = y[keep, t].astype(np.float64) * sc[0] + sc[1], p[keep, t].astype(np.float64) * sc[0] + sc[1]
+            assert rows[t, 4] == MR.swapped_pairs(yt, pt) and rows[t, 5] == MR.n_pairs(yt), (c, t)
+            assert _close(rows[t, 0], MR.rms_score(yt, pt)), (c, t)
+        assert got[4] == rows[:, 4].sum() and got[5] == rows[:, 5].sum()
+
+
 @pytest.mark.gpu
 def test_device_metrics_equal_golden_cases(device):
     from jova_amd.metrics import dti_metrics

@@ -9,6 +9,9 @@ torch seed (a per-parameter checksum is stored so the test can prove it rebuilt 
   nonsat_evals, nonsat_margin                       evaluations of the nonsat loop and |mean|delta|| - ep| at the stop
   per parameter tensor k
       gs64.<k>    a fixed strided sample (<= 2048 elements) of the double-run gradient
+      gp64.<k>    8 projections of the WHOLE double-run gradient on seeded +-1 vectors (proj_vectors): with them the CPU
+                  test pins every element of the fp64 oracle's gradient to the reference's (two double runs have no mask
+                  flips, so the projections agree to 1e-9), and the GPU test then compares whole tensors with that oracle
       gstat.<k>   [L2(g64), max|g64|, max|g32 - g64|, L2(g32 - g64)]  (the last two: largest of three fp32 runs that
                   differ in CPU thread count, i.e. in summation order)
       wsum.<k>    integer checksum of the initial parameter's fp32 bit patterns (exact, order-independent)
@@ -46,6 +49,10 @@ WORKLOADS = {
     "metz_psc_b128": ("metz", 1, 160, 96, 8, 64, 128, TUNED, ["pcnn2d", "psc"]),
     "davis_b256_default": ("davis", 64, None, None, 1, 1, 256, DEFAULT, ["pcnn2d"]),
     "long1024_b128": ("long1024", 1, 160, 48, 64, 8, 128, TUNED, ["pcnn2d"]),
+    # BASELINE config 5, the multi-task ("full ToxCast") variant: output_dim = len(tasks) = 12 (train_joint_attn.py:1027,
+    # :238), ~70 % of the labels missing (w = 0, y = 0 there, as DeepChem pads missing labels), Metz-shaped molecules +
+    # PSC view; loss = MSELoss(outputs * w, y) over all B x T entries (:464-465)
+    "metz_psc_t12_b128": ("metz", 8, 160, 96, 1, 8, 128, dict(TUNED, out_dim=12, missing=0.7), ["pcnn2d", "psc"]),
 }
 
 
@@ -84,7 +91,7 @@ def build_net(hp, profile, views):
     for d in hp["lin_dims"]:
         layers += [nn.Linear(p, d), nn.BatchNorm1d(d), nn.ReLU(), nn.Dropout(dp)]
         p = d
-    layers.append(nn.Linear(p, 1))
+    layers.append(nn.Linear(p, hp.get("out_dim", 1)))
     return nn.Sequential(*layers)
 
 
@@ -94,7 +101,26 @@ def make_inputs(tag):
     mi, pi, y, w = pool.sample_pairs(np.random.RandomState(pair_seed), bsz)
     if shape == "long1024":
         pi[0] = 0                                         # protein 0 of that shape has exactly 1024 segments
+    y, w = task_labels(hp, pair_seed, y, w)
     return pool, mi, pi, y, w
+
+
+def task_labels(hp, pair_seed, y, w):
+    """[B, T] labels and weights of a multi-task workload (mirrored by tests/helpers.py:full_setup)."""
+    T = hp.get("out_dim", 1)
+    if T == 1:
+        return y, w
+    r = np.random.RandomState(pair_seed + 7919)
+    y = r.normal(size=(y.shape[0], T))
+    w = (r.uniform(size=y.shape) >= hp["missing"]).astype(np.float64)
+    return y * w, w
+
+
+def proj_vectors(name, numel, k=8):
+    """k seeded +-1 vectors for the whole-tensor projections of parameter `name` (mirrored by tests/helpers.py)."""
+    import zlib
+    r = np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    return r.randint(0, 2, size=(k, numel)).astype(np.float64) * 2.0 - 1.0
 
 
 def run_reference(tag, double):
@@ -173,6 +199,7 @@ def gen(tag):
         g32 = r32["grads"][k]
         idx = sample_index(g64.size)
         arrays["gs64." + k] = g64.reshape(-1)[idx]
+        arrays["gp64." + k] = proj_vectors(k, g64.size) @ g64.reshape(-1)
         d = g32 - g64
         dmax = max(float(np.abs(r["grads"][k] - g64).max()) for r in runs32)
         dl2 = max(float(np.sqrt(((r["grads"][k] - g64) ** 2).sum())) for r in runs32)
