@@ -131,7 +131,13 @@ void jova_nonsat_set_spin_limit(uint64_t ticks);
  * GFLOP or more on aligned shapes run on the bf16 matrix pipe at fp32 accuracy: operands split into three bf16 pieces,
  * six piece products, fp32 accumulation (jova_gemm_f32 / jova_linear_bwd_weight choose it by themselves; forward
  * products never take it).  on = 0 keeps them on the fp32 MFMA kernel, as does JOVA_GEMM_NO_BF16X3 in the environment;
- * process-wide.  No counterpart in the reference. */
+ * process-wide.  No counterpart in the reference.
+ * Operand range of that form: finite operands with |x| <= 3.3895e38 (the largest bfloat16; an fp32 value above it, i.e.
+ * within 2^-8 of FLT_MAX, rounds its top piece to infinity and the outputs it feeds are NaN where an fp32 chain stays
+ * finite), full fp32 accuracy for |x| >= 2^-110 (below that the smallest of the three pieces, 2^-16 |x|, leaves the normal
+ * range and the product degrades gracefully towards bf16 x 2 accuracy); zeros are exact; a non-finite operand gives NaN
+ * (fp32 would give +-inf).  tests/test_gpu_ops.py::test_bf16_pieces_operand_range pins both ends.  Gradients of a
+ * training step sit many decades inside this range; data that do not: jova_gemm_set_bf16x3(0). */
 void jova_gemm_set_bf16x3(int on);
 /* the switch's current value (1 = on), the environment default resolved: lets a caller put back what it found */
 int jova_gemm_get_bf16x3(void);
@@ -313,6 +319,9 @@ int jova_dti_metrics_tasks(const float* y_true, const float* y_pred, const float
 int jova_relu_fwd(const float* x, int64_t n, float* y, void* stream);
 int jova_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* stream);
 int jova_axpy(const float* x, float a, int64_t n, float* y, void* stream);
+/* y = x * (*a_dev): the factor is a DEVICE scalar (the gradient that reaches nn.MSELoss's backward, train_joint_attn.py:465
+ * and :485, without a host read or a broadcast copy) */
+int jova_scale_dev(const float* x, const float* a_dev, int64_t n, float* y, void* stream);
 /* p[0..n) = 0 as a kernel on the stream (optimizer.zero_grad(), proj/dti/train_joint_attn.py:428, on the flat gradient
  * buffer; a kernel rather than a memset so that it replays reliably inside a captured hipGraph) */
 int jova_zero(float* p, int64_t n, void* stream);

@@ -57,6 +57,7 @@ _SIGS = {
     "jova_relu_bwd": "ppqpp",
     "jova_axpy": "pfqpp",
     "jova_zero": "pqp",
+    "jova_scale_dev": "ppqpp",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "q": ctypes.c_int64, "f": ctypes.c_float, "Q": ctypes.c_uint64,
        "d": ctypes.c_double}

@@ -438,6 +438,20 @@ extern "C" int jova_relu_bwd(const float* dy, const float* y, int64_t n, float* 
     return JOVA_OK;
 }
 
+__global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ a, long long n,
+                                 float* __restrict__ y) {
+    const float s = *a;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+        y[e] = x[e] * s;
+}
+extern "C" int jova_scale_dev(const float* x, const float* a_dev, int64_t n, float* y, void* stream) {
+    JOVA_CHECK_ARG(n >= 0 && a_dev && (n == 0 || (x && y)), "scale_dev: bad argument");
+    if (n == 0) return JOVA_OK;
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, a_dev, (long long)n, y);
+    JOVA_CHECK_LAUNCH("scale_dev");
+    return JOVA_OK;
+}
+
 extern "C" int jova_zero(float* p, int64_t n, void* stream) {
     JOVA_CHECK_ARG(n >= 0 && (n == 0 || p), "zero: bad argument");
     if (n == 0) return JOVA_OK;

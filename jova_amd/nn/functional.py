@@ -24,7 +24,28 @@ def _empty(shape, like, dtype=_F32):
 
 
 def _zeros(shape, like, dtype=_F32):
-    return torch.zeros(shape, dtype=dtype, device=like.device)
+    """Zero-filled device tensor; the fill is the library's own kernel on the stream (no torch math on the hot path)."""
+    t = torch.empty(shape, dtype=dtype, device=like.device)
+    if t.is_cuda and dtype == _F32 and t.numel():
+        call("jova_zero", P(t), t.numel(), stream())
+        return t
+    return t.zero_()
+
+
+_SEG_OFF = {}
+
+
+def _seg_off_device(seg_off, device):
+    """int32 device copy of a view-offset list, made once per distinct (list, device): JointAttention runs every step with
+    one of a handful of (1, A_max, P_max) combinations, and a pageable host->device copy per call would sit in the stream
+    (and could not be captured into a hipGraph)."""
+    key = (tuple(seg_off), device)
+    t = _SEG_OFF.get(key)
+    if t is None:
+        if len(_SEG_OFF) > 4096:
+            _SEG_OFF.clear()
+        t = _SEG_OFF[key] = torch.tensor(seg_off, dtype=torch.int32).to(device)
+    return t
 
 
 def _c(t):
@@ -705,7 +726,7 @@ class JointAttentionFunction(torch.autograd.Function):
             call("jova_layernorm_fwd", P(f), P(x1), P(g2), P(be2), T, L, 1e-5, P(x2), P(mr2), stream())
             saved.append((x, qkv, probs, o, xp, x1, mr1, hid, f, mr2, pd if p_drop > 0 else None))
             x = x2
-        seg_off_dev = torch.tensor(seg_off, dtype=torch.int32).to(ref.device, non_blocking=True)
+        seg_off_dev = _seg_off_device(seg_off, ref.device)
         out = _empty((bsz, n_views * L), ref)
         call("jova_viewpool_fwd", P(x), P(seg_off_dev), n_views, bsz, L, P(out), stream())
         ctx.cfg = (n_views, H, num_layers, p_drop, bsz, L, segs, S, Sp, T, hd, seg_off, seg_off_dev)
@@ -991,7 +1012,6 @@ class MSELossFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         (dout,) = ctx.saved_tensors
-        scale = dloss.reshape(1).to(dout.dtype).expand(dout.numel()).contiguous()
         g = torch.empty_like(dout)
-        call("jova_mul", P(dout), P(scale), dout.numel(), P(g), stream())
+        call("jova_scale_dev", P(dout), P(_c(dloss.reshape(1).to(dout.dtype))), dout.numel(), P(g), stream())
         return g, None, None

@@ -133,6 +133,101 @@ def test_backward_products_from_bf16_pieces_are_fp32_accurate(device, mode):
             assert not torch.equal(dx32, dx), "the switch changed nothing: both calls took the same kernel"
 
 
+def _fp32_chain_error(a, b, ref64, scale):
+    """Error of the plain fp32 multiply-add chain  sum_k a[:, k] b[k, :]  (one rounding per term) against fp64, in units of
+    `scale` per output row: the yard-stick of the bf16-pieces products."""
+    acc = torch.zeros(a.shape[0], b.shape[1])
+    for k in range(a.shape[1]):
+        acc += a[:, k:k + 1] * b[k:k + 1, :]
+    return ((acc.double() - ref64).abs() / scale).max().item()
+
+
+@pytest.mark.parametrize("case", ["dx_k2048", "dw_splitk", "dw_one_part"])
+def test_bf16_pieces_second_shapes(device, case):
+    """a second shape per kernel form.  dX with a 2048-long contraction (LDS-DMA form: the FFN
+    linear2 data gradient), dW with split-K over 8192 rows and dW in one part (register-staged form)."""
+    from jova_amd.nn import functional as F_
+    from jova_amd._lib import lib
+    if not lib().jova_gemm_get_bf16x3():
+        pytest.skip("bf16-pieces products are switched off (JOVA_GEMM_NO_BF16X3)")
+    g = torch.Generator().manual_seed(77)
+    if case == "dx_k2048":
+        M, N, K = 2048, 2048, 512                                  # dy [M, N] w [N, K]: contraction over N = 2048
+        dy = torch.randn(M, N, generator=g) * torch.exp(4.0 * torch.randn(M, 1, generator=g))
+        w = torch.randn(N, K, generator=g)
+        ref64 = dy.double() @ w.double()
+        scale = ref64.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
+        err32 = _fp32_chain_error(dy, w, ref64, scale)
+        dx = torch.full((M, K), float("nan"), device=device)
+        F_.linear_bwd_data(dy.to(device), w.to(device), dx)
+        err = ((dx.cpu().double() - ref64).abs() / scale).max().item()
+    else:
+        rows, n_out, k_in = (8192, 512, 2048) if case == "dw_splitk" else (1024, 2048, 2048)
+        dy = torch.randn(rows, n_out, generator=g) * torch.exp(3.0 * torch.randn(1, n_out, generator=g))
+        x = torch.randn(rows, k_in, generator=g)
+        ref64 = dy.double().t() @ x.double()
+        scale = ref64.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
+        err32 = _fp32_chain_error(dy.t().contiguous(), x, ref64, scale)
+        dw = torch.zeros(n_out, k_in, device=device)
+        F_.linear_bwd_weight(dy.to(device), x.to(device), dw, None)
+        err = ((dw.cpu().double() - ref64).abs() / scale).max().item()
+    assert err <= max(2e-6, 1.5 * err32), "%s: %.3e of the row scale, fp32 chain %.3e" % (case, err, err32)
+
+
+@pytest.mark.parametrize("form", ["dx", "dw"])
+def test_bf16_pieces_operand_range(device, form):
+    """The input range of the bf16-pieces products, pinned at both ends (include/jova_hip.h, jova_gemm_set_bf16x3):
+      * top: operands up to 3.38e38 (the largest bfloat16 is 3.3895e38; fp32 goes to 3.4028e38) are handled at fp32
+        accuracy; an operand above the bfloat16 range rounds its top piece to infinity and the affected outputs are NaN
+        where an fp32 chain stays finite -- the documented limit, asserted here so that it cannot change silently;
+      * bottom: operands down to 1e-32 keep all three pieces normal (the smallest piece is 2^-16 of the operand) and are
+        handled at fp32 accuracy; exact zeros stay exact."""
+    from jova_amd.nn import functional as F_
+    from jova_amd._lib import lib
+    if not lib().jova_gemm_get_bf16x3():
+        pytest.skip("bf16-pieces products are switched off (JOVA_GEMM_NO_BF16X3)")
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 2048, 1024, 512
+
+    def run(a, b):                                                 # a [M, N], b [N, K] -> a b through the chosen form
+        if form == "dx":
+            out = torch.full((M, K), float("nan"), device=device)
+            F_.linear_bwd_data(a.to(device), b.to(device), out)
+        else:                                                      # dw[n_out = M, k_in = K] = dy^T x with dy = a^T
+            out = torch.zeros(M, K, device=device)
+            F_.linear_bwd_weight(a.t().contiguous().to(device), b.to(device), out, None)
+        return out.cpu().double()
+
+    sign = torch.where(torch.rand(M, N, generator=g) < 0.5, -1.0, 1.0)
+    for name, lo, hi, bscale in (("top", 1.0e38, 3.38e38, 1e-6), ("bottom", 1.0e-32, 4.0e-32, 1e3)):
+        a = sign * (lo + (hi - lo) * torch.rand(M, N, generator=g))
+        a[:, 7] = 0.0                                              # exact zeros ride along
+        b = torch.randn(N, K, generator=g) * bscale
+        ref64 = a.double() @ b.double()
+        assert float(ref64.abs().max()) < 3.0e38 and float(ref64.abs().max()) > 1e-36
+        scale = ref64.abs().amax(dim=1, keepdim=True)
+        err32 = _fp32_chain_error(a, b, ref64, scale)
+        got = run(a, b)
+        assert torch.isfinite(got).all(), name
+        err = ((got - ref64).abs() / scale).max().item()
+        assert err <= max(2e-6, 1.5 * err32), "%s of the range: %.3e of the row scale, fp32 chain %.3e" % (name, err, err32)
+    # above the bfloat16 range: the documented limit
+    a = torch.randn(M, N, generator=g)
+    a[5, 11] = 3.4e38                                              # finite in fp32, beyond the largest bfloat16
+    b = torch.randn(N, K, generator=g) * 1e-3
+    got = run(a, b)
+    assert not torch.isfinite(got[5]).all(), "an operand above 3.3895e38 is expected to poison its output row"
+    keep = torch.ones(M, dtype=torch.bool)
+    keep[5] = False
+    assert torch.isfinite(got[keep]).all()
+    was = lib().jova_gemm_get_bf16x3()
+    lib().jova_gemm_set_bf16x3(0)                                 # the fp32 MFMA kernel handles it: the way out for such data
+    try:
+        assert torch.isfinite(run(a, b)).all()
+    finally:
+        lib().jova_gemm_set_bf16x3(was)
+
+
 @pytest.mark.parametrize("shape", [(241, 241, 256, 32, 2), (256, 203, 64, 64, 1), (130, 250, 16, 3, 40)])
 def test_gemm_ragged_batched_aligned_form(device, shape):
     """The per-(b,h) attention products with K = head_dim (scores = Q K^T, dP = dO V^T) take the aligned kernel although S
