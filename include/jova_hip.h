@@ -272,6 +272,13 @@ int jova_embedding_bwd(const float* dout, const int64_t* idx, int64_t n, int d, 
  * "sum"); x NULL = the scaled y alone (backward). */
 int jova_rowscale_add(const float* x_or_null, const float* y, const float* m_or_null, int64_t rows, int cols, float* out,
                       void* stream);
+/* The matmul of update_fingerprints itself (models.py:366-371: torch.matmul(adjacency_matrices, hs)) for an adjacency kept
+ * in CSR form: out [n_rows, d] = A x, A given by row_ptr int32 [n_rows + 1], col int32 [nnz] (rows of x, < n_src; an index
+ * outside yields NaN), val [nnz] (NULL = all ones).  The reference builds the batch's block-diagonal matrix dense
+ * ([N, N] fp32, jova/data/data.py:309-335); jova_amd.data keeps the per-molecule non-zeros.  Backward = the same call
+ * with the CSR form of A^T. */
+int jova_spmm_csr(const int32_t* row_ptr, const int32_t* col, const float* val_or_null, const float* x, int64_t n_rows,
+                  int d, int64_t n_src, float* out, void* stream);
 
 /* ---- ProteinRNN (jova/nn/models.py:657-682): single-layer one-directional nn.LSTM, zero initial state, section 8(f3) --
  * gx [T, B, 4H] = x W_ih^T + b_ih + b_hh for all steps (one jova_gemm_f32 by the caller; gate order i | f | g | o),

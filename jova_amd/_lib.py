@@ -53,6 +53,7 @@ _SIGS = {
     "jova_gauss_hist_bwd": "ppqfpp",
     "jova_lstm_fwd": "ppiiipppp", "jova_lstm_bwd": "ppppiiipp",
     "jova_embedding_fwd": "ppqiqppp", "jova_embedding_bwd": "ppqiqpp", "jova_rowscale_add": "pppqipp",
+    "jova_spmm_csr": "ppppqiqpp",
     "jova_relu_fwd": "pqpp",
     "jova_relu_bwd": "ppqpp",
     "jova_axpy": "pfqpp",

@@ -10,6 +10,8 @@ What differs is underneath: the batch merge is native (jova_collate_gconv) and e
 asynchronous copy; tensors land on the current CUDA device when there is one (the reference's ``cuda()`` helper,
 jova/utils/train_helpers or data.py ``cuda``), else stay on the CPU.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -111,17 +113,69 @@ def process_weave_view_data(X, prot_desc_dict, idx, cuda_prot):
     return mol_data, prots_tensor, prot_names, x_data
 
 
-def process_gnn_view_data(X, prot_desc_dict, idx, cuda_prot):
+def process_gnn_view_data(X, prot_desc_dict, idx, cuda_prot, dense=None):
     """data.py:309-335 -> (mol_data, prots_tensor, prot_names, x_data) with
-    mol_data = (fingerprints int64 [N], block-diagonal adjacency float [N, N], M float [N, 1], axis = atoms per molecule).
-    The block-diagonal matrix, M and the ids are laid out in ONE pinned buffer and go up in one copy (the reference
-    uploads every molecule's fingerprint tensor by itself and builds the block matrix with torch ops)."""
+    mol_data = (fingerprints int64 [N], block-diagonal adjacency, M float [N, 1], axis = atoms per molecule).
+
+    The adjacency: the reference builds the dense block-diagonal float matrix [N, N] (67 MB at N = 4.1 k, 99.9 % zeros)
+    and multiplies by it in every layer.  ``dense=False`` (the default on the GPU) hands the model a
+    nn.functional.BlockAdjacency instead: the non-zeros of every molecule's matrix in CSR form (A and A^T), which
+    GraphNeuralNet multiplies with jova_spmm_csr; ``.to_dense()`` gives the reference's tensor.  ``dense=True`` (the
+    default on the CPU, JOVA_GNN_DENSE=1 anywhere) is the reference's layout: block matrix, M and ids laid out in ONE pinned
+    buffer that goes up in one copy (the reference uploads every molecule's fingerprint tensor by itself and builds the block
+    matrix with torch ops)."""
     x_data = X[:, 0, idx]
     mols = [pair[0] for pair in x_data]
     axis = [len(m.fingerprints) for m in mols]
     n = int(sum(axis))
     dev = _device()
     pin = dev.type == "cuda"
+    if dense is None:
+        dense = dev.type != "cuda" or bool(os.environ.get("JOVA_GNN_DENSE"))
+    if not dense:
+        from ..nn.functional import BlockAdjacency
+        rows, cols, vals, o = [], [], [], 0
+        for m, k in zip(mols, axis):
+            a = np.asarray(m.adjacency, dtype=np.float32)
+            r, c = np.nonzero(a)
+            rows.append(r + o)
+            cols.append(c + o)
+            vals.append(a[r, c])
+            o += k
+        rows = np.concatenate(rows) if rows else np.zeros(0, np.int64)
+        cols = np.concatenate(cols) if cols else np.zeros(0, np.int64)
+        vals = np.concatenate(vals).astype(np.float32) if vals else np.zeros(0, np.float32)
+        nnz = int(rows.size)
+
+        def csr(r, c, v):                                   # r sorted or not: a stable sort by row keeps column order
+            order = np.argsort(r, kind="stable")
+            ptr = np.zeros(n + 1, np.int32)
+            np.cumsum(np.bincount(r, minlength=n), out=ptr[1:])
+            return ptr, c[order].astype(np.int32), v[order]
+        p0, c0, v0 = csr(rows, cols, vals)
+        p1, c1, v1 = csr(cols, rows, vals)
+        # one pinned image: ptr | col | val | ptr_t | col_t | val_t | M | ids (int64 = two 4-byte words each)
+        words = 2 * (n + 1) + 4 * nnz + n + (n & 1)
+        buf = torch.empty(words + 2 * n, dtype=torch.int32, pin_memory=pin)
+        hb = buf.numpy()
+        offs, o = [], 0
+        for arr in (p0, c0, v0, p1, c1, v1):
+            hb[o:o + arr.size] = arr.view(np.int32)
+            offs.append((o, arr.size))
+            o += arr.size
+        o_m = o
+        mv = np.repeat(np.asarray(axis, dtype=np.float32), axis)
+        hb[o_m:o_m + n] = mv.view(np.int32)
+        ids = buf[words:].view(torch.int64).numpy()
+        ids[:] = np.concatenate([np.asarray(m.fingerprints, dtype=np.int64) for m in mols]) if mols else 0
+        d = buf.to(dev, non_blocking=True)
+        part = [d[a:a + k] for a, k in offs]
+        f32 = lambda t: t.view(torch.float32)              # noqa: E731
+        adj = BlockAdjacency(n, part[0], part[1], f32(part[2]), part[3], part[4], f32(part[5]))
+        adj._keepalive = (buf, d)
+        mol_data = (d[words:].view(torch.int64), adj, f32(d[o_m:o_m + n]).view(n, 1), axis)
+        prots_tensor, prot_names = _protein_tensor(x_data, prot_desc_dict, cuda_prot)
+        return mol_data, prots_tensor, prot_names, x_data
     buf = torch.empty(n * n + n + 2 * n, dtype=torch.float32, pin_memory=pin)     # A | M | ids (int64 = 2 floats each)
     a = buf[:n * n].view(n, n).numpy()
     a[:] = 0.0

@@ -844,20 +844,44 @@ class EmbeddingFunction(torch.autograd.Function):
             raise IndexError("index out of range in self (fingerprint id outside the embedding table)")
 
 
+class BlockAdjacency(object):
+    """The batch's block-diagonal adjacency of the gnn view as its non-zeros (CSR of A and of A^T, device int32 / fp32)
+    instead of the reference's dense [N, N] matrix (jova/data/data.py:309-335: 67 MB at N = 4.1 k, 99.9 % zeros).
+    ``to_dense()`` gives the reference's tensor.  Made by jova_amd.data.data.process_gnn_view_data."""
+
+    def __init__(self, n, row_ptr, col, val, row_ptr_t, col_t, val_t):
+        self.n, self.shape = int(n), (int(n), int(n))
+        self.row_ptr, self.col, self.val = row_ptr, col, val
+        self.row_ptr_t, self.col_t, self.val_t = row_ptr_t, col_t, val_t
+        self.device, self.is_cuda = row_ptr.device, row_ptr.is_cuda
+
+    def to_dense(self):
+        rp = self.row_ptr.cpu().numpy()
+        rows = np.repeat(np.arange(self.n), np.diff(rp))
+        a = torch.zeros(self.shape, dtype=_F32)
+        a[torch.from_numpy(rows), self.col.cpu().long()] = self.val.cpu()
+        return a.to(self.device)
+
+
 class GnnUpdateFunction(torch.autograd.Function):
     """x + (A @ hs) / (M - 1)  ('mean')  or  x + A @ hs  ('sum'): GraphNeuralNet.update_fingerprints after its Linear + ReLU
-    (jova/nn/models.py:364-372).  A is the block-diagonal adjacency the reference's collator hands over ([N, N] fp32, no
-    gradient): one fp32 MFMA GEMM forward, one (A^T) backward."""
+    (jova/nn/models.py:364-372).  A (no gradient) is either the dense block-diagonal matrix the reference's collator hands
+    over ([N, N] fp32: one fp32 MFMA GEMM forward, one with A^T backward) or a BlockAdjacency (this package's collator:
+    the non-zeros only, jova_spmm_csr forward and backward)."""
 
     @staticmethod
     def forward(ctx, x, hs, A, M):
-        x, hs, A = _c(x), _c(hs), _c(A)
+        x, hs = _c(x), _c(hs)
         n, d = x.shape
-        if A.shape != (n, n):
+        if tuple(A.shape) != (n, n):
             raise RuntimeError("adjacency is %s for %d nodes" % (tuple(A.shape), n))
         m = None if M is None else _c(M).reshape(-1)
         tmp = _empty((n, d), x)
-        gemm(_addr(A), n, 1, _addr(hs), d, 1, _addr(tmp), d, n, d, n)
+        if isinstance(A, BlockAdjacency):
+            call("jova_spmm_csr", P(A.row_ptr), P(A.col), P(A.val), P(hs), n, d, n, P(tmp), stream())
+        else:
+            A = _c(A)
+            gemm(_addr(A), n, 1, _addr(hs), d, 1, _addr(tmp), d, n, d, n)
         out = _empty((n, d), x)
         call("jova_rowscale_add", P(x), P(tmp), P(m), n, d, P(out), stream())
         ctx.A, ctx.m = A, m
@@ -872,7 +896,11 @@ class GnnUpdateFunction(torch.autograd.Function):
             g = torch.empty_like(dout)
             call("jova_rowscale_add", None, P(dout), P(ctx.m), n, d, P(g), stream())
         dhs = _empty((n, d), dout)
-        gemm(_addr(ctx.A), 1, n, _addr(g), d, 1, _addr(dhs), d, n, d, n)          # A^T g
+        A = ctx.A
+        if isinstance(A, BlockAdjacency):
+            call("jova_spmm_csr", P(A.row_ptr_t), P(A.col_t), P(A.val_t), P(g), n, d, n, P(dhs), stream())     # A^T g
+        else:
+            gemm(_addr(A), 1, n, _addr(g), d, 1, _addr(dhs), d, n, d, n)          # A^T g
         return dout, dhs, None, None
 
 

@@ -93,7 +93,11 @@ class GraphNeuralNet(nn.Module):
 
     def _node_vectors(self, inputs):
         fingerprints, adjacency_matrices, M, axis = inputs
-        F_._lib.require_gpu(fingerprints, adjacency_matrices, M)
+        F_._lib.require_gpu(fingerprints, M)
+        if not isinstance(adjacency_matrices, F_.BlockAdjacency):
+            F_._lib.require_gpu(adjacency_matrices)
+        elif not adjacency_matrices.is_cuda:
+            raise RuntimeError("jova_amd: tensors must live on the GPU (the HIP path has no CPU fallback)")
         x = F_.EmbeddingFunction.apply(self.embed_fingerprint.weight, fingerprints)
         for lin in self.W_gnn:
             hs = F_.LinearFunction.apply(x, lin.weight, lin.bias, True)

@@ -80,6 +80,52 @@ def test_gnn2d_equals_the_reference_golden(device, update):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("update", ["mean", "sum"])
+def test_gnn2d_on_the_sparse_block_adjacency_equals_the_reference_golden(device, update):
+    """The collator's GPU form of the adjacency (BlockAdjacency: CSR of every molecule's block, jova_spmm_csr forward and
+    backward) against the same reference-made golden as the dense form, its to_dense() against the reference's matrix, and
+    an ASYMMETRIC adjacency (A != A^T) against the dense path, so the backward really uses A^T."""
+    from jova_amd.data import data as D
+    from jova_amd.nn import functional as F_
+    from jova_amd.nn.models import GraphNeuralNet2D
+    z = H.load("op_gnn2d")
+    n_fp, dim, layers = [int(v) for v in z["cfg"]]
+    mols = _golden_mols(z)
+    X = np.empty((len(mols), 3, 1), dtype=object)
+    for k, m in enumerate(mols):
+        X[k, 0, 0] = (m, _Prot("P0"))
+    (fp, A, M, axis), _, _, _ = D.process_gnn_view_data(X, {"P0": np.zeros((1, 5), np.float32)}, 0, cuda_prot=False)
+    assert isinstance(A, F_.BlockAdjacency) and A.is_cuda and fp.is_cuda
+    assert np.array_equal(A.to_dense().cpu().numpy(), z["A"]) and np.array_equal(M.cpu().numpy(), z["M"])
+    assert np.array_equal(fp.cpu().numpy(), z["fingerprints"]) and axis == z["axis"].tolist()
+    net = GraphNeuralNet2D(n_fp, dim, num_layers=layers, update=update)
+    net.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")})
+    net = net.to(device)
+    out = net((fp, A, M, axis))
+    (out * torch.from_numpy(z[update + ".gout"]).to(device)).sum().backward()
+    H.assert_close(out, z[update + ".out"], tol=1e-5, what="out")
+    for k, p in net.named_parameters():
+        H.assert_close(p.grad, z[update + ".grad." + k], tol=2e-5, what="grad " + k)
+    # asymmetric, weighted adjacency: sparse and dense paths agree (forward and the A^T of the backward)
+    rng = np.random.RandomState(3)
+    for m in mols:
+        m.adjacency = (m.adjacency * rng.uniform(0.5, 1.5, size=m.adjacency.shape)).astype(np.float32)
+        m.adjacency[0, -1] = 0.0
+    (fp, A2, M, axis), _, _, _ = D.process_gnn_view_data(X, {"P0": np.zeros((1, 5), np.float32)}, 0, cuda_prot=False)
+    dense = A2.to_dense()
+    assert not torch.equal(dense, dense.t())
+    grads = []
+    for adj in (A2, dense):
+        net.zero_grad()
+        o = net((fp, adj, M, axis))
+        (o * torch.from_numpy(z[update + ".gout"]).to(device)).sum().backward()
+        grads.append((o.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}))
+    H.assert_close(grads[0][0], grads[1][0], tol=2e-6, what="sparse vs dense out")
+    for k in grads[0][1]:
+        H.assert_close(grads[0][1][k], grads[1][1][k], tol=1e-5, what="sparse vs dense grad " + k)
+
+
+@pytest.mark.gpu
 def test_gnn_embedding_flags_an_id_outside_the_table(device):
     from jova_amd.nn import functional as F_
     w = torch.randn(5, 4, device=device)

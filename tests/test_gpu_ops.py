@@ -954,8 +954,17 @@ def test_davis_full_size_stages_vs_oracle(device):
     ja_hip = net[1](vg)
     held(ja_hip, s32["ja"], s64["ja"], "joint-attention output")
     ja_hip.backward(f32(d_ja64))
+    # the view gradients: the bound takes the SMALLER of the fp32 oracle's distance and the reference's own fp32 scatter
+    # (eight summation orders of the imported reference's JointAttention from these stage inputs,
+    # stage_noise_davis_b128.npz): 8e-7 for the fingerprint and graph views, i.e. the north-star 1e-5 binds there
+    noise = H.load("stage_noise_davis_b128")
     for i in range(3):
-        held(vg[i].grad, s32["views"][i].grad, d_views64[i], "d loss / d view %d" % i)
+        e_ref = float(noise["d_view%d" % i].max())
+        e_o32 = H.rel_err(s32["views"][i].grad.detach().double().numpy(), d_views64[i].detach().double().numpy())
+        e = H.rel_err(vg[i].grad.detach().cpu().double().numpy(), d_views64[i].detach().double().numpy())
+        bound = max(1e-5, 2 * min(e_ref, e_o32))
+        assert e <= bound, "d loss / d view %d: err %.3e > %.3e (reference fp32 scatter %.3e, fp32 oracle %.3e)" % (
+            i, e, bound, e_ref, e_o32)
     check(["1."])
     # graph view and protein view
     tr.flat.zero_grad()

@@ -277,9 +277,82 @@ def gen_nonsat_margin():
     np.savez_compressed(os.path.join(MG.OUT, "op_nonsat_margin.npz"), **arrays)
 
 
+def gen_stage_noise(tag="davis_b128", thread_counts=(8, 1, 2, 3, 4, 5, 6, 7)):
+    """What the REFERENCE's own fp32 arithmetic does to the joint-attention stage when only its summation order changes
+    (CPU thread count): JointAttention + its view gradients run in fp32 from the double run's stage inputs (views) and
+    upstream gradient, once per thread count, each compared with the double run.  -> tests/golden/stage_noise_<tag>.npz:
+    per quantity the distances max|x32 - x64| / max|x64| of every run.  The stage-wise GPU test
+    (tests/test_gpu_ops.py::test_davis_full_size_stages_vs_oracle) takes its bound for the quantities that depend on the
+    6e7 FFN ReLU masks from these, next to the fp32 oracle's own distance."""
+    shape, pseed, n_mols, n_prots, pair_seed, wseed, bsz, hp, views = WORKLOADS[tag]
+    pool, mi, pi, y, w = make_inputs(tag)
+    torch.manual_seed(wseed)
+    net = build_net(hp, pool.protein_profile, views).train()
+    mols = [pool.mols[i] for i in mi]
+    mm, glist = MG.ref_batch(mols)
+    names = [("synthetic", pool.prot_names[i]) for i in pi]
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    saved_float = torch.Tensor.float
+    try:                                                   # the double run, stage by stage
+        net64 = build_net(hp, pool.protein_profile, views).train()
+        net64.load_state_dict(sd)
+        net64 = net64.double()
+        torch.Tensor.float = lambda self, *a, **k: self.double()
+        torch.set_default_dtype(torch.float64)
+        X = [torch.from_numpy(pool.ecfp[mi]).double(), (glist, bsz), names]
+        v64 = [t.detach().requires_grad_(True) for t in net64[0](X)]
+        ja64 = net64[1](v64)
+        out = ja64
+        for i in range(2, len(net64)):
+            out = net64[i](out)
+        loss = nn.MSELoss()(out * torch.from_numpy(w).double(), torch.from_numpy(y).double())
+        loss.backward()
+        d_views64 = [t.grad.detach().clone() for t in v64]
+        g64 = {k: p.grad.detach().clone() for k, p in net64[1].named_parameters()}
+        # upstream gradient of the stage: d loss / d (joint-attention output)
+        ja_leaf = ja64.detach().requires_grad_(True)
+        o2 = ja_leaf
+        for i in range(2, len(net64)):
+            o2 = net64[i](o2)
+        nn.MSELoss()(o2 * torch.from_numpy(w).double(), torch.from_numpy(y).double()).backward()
+        d_ja64 = ja_leaf.grad.detach().clone()
+    finally:
+        torch.Tensor.float = saved_float
+        torch.set_default_dtype(torch.float32)
+
+    def rel(a, b):
+        return float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-300))
+
+    rows = {}
+    for threads in thread_counts:
+        torch.set_num_threads(threads)
+        net32 = build_net(hp, pool.protein_profile, views).train()
+        net32.load_state_dict(sd)
+        v32 = [t.detach().float().requires_grad_(True) for t in v64]
+        ja32 = net32[1](v32)
+        ja32.backward(d_ja64.float())
+        rows.setdefault("ja", []).append(rel(ja32.detach(), ja64.detach()))
+        for i, t in enumerate(v32):
+            rows.setdefault("d_view%d" % i, []).append(rel(t.grad, d_views64[i]))
+        num = sum(float(((p.grad.double() - g64[k]) ** 2).sum()) for k, p in net32[1].named_parameters())
+        den = sum(float((g64[k] ** 2).sum()) for k in g64)
+        rows.setdefault("param_l2", []).append((num / den) ** 0.5)
+        for k, p in net32[1].named_parameters():
+            rows.setdefault("g." + k, []).append(rel(p.grad, g64[k]))
+    torch.set_num_threads(8)
+    arrays = {k: np.array(v) for k, v in rows.items()}
+    arrays["threads"] = np.array(thread_counts)
+    arrays["spec"] = np.array(json.dumps(dict(tag=tag, pool_seed=pseed, pair_seed=pair_seed, weight_seed=wseed, batch=bsz)))
+    np.savez_compressed(os.path.join(MG.OUT, "stage_noise_" + tag + ".npz"), **arrays)
+    for k in ("ja", "d_view0", "d_view1", "d_view2", "param_l2"):
+        print("stage noise %-9s %s" % (k, " ".join("%.2e" % v for v in rows[k])), flush=True)
+
+
 if __name__ == "__main__":
-    for tag in (sys.argv[1:] or (list(WORKLOADS) + ["nonsat_margin"])):
+    for tag in (sys.argv[1:] or (list(WORKLOADS) + ["nonsat_margin", "stage_noise"])):
         if tag == "nonsat_margin":
             gen_nonsat_margin()
+        elif tag == "stage_noise":
+            gen_stage_noise()
         else:
             gen(tag)
