@@ -31,6 +31,7 @@ from jova_amd.train import TUNED_DAVIS_HPARAMS, Trainer, count_parameters, creat
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32) dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 matrix dense peak (v_mfma_f32_32x32x16_bf16)
 
 
 # name -> (synthetic shape, protein views, description)
@@ -443,12 +444,14 @@ def main():
     _jova_lib().jova_gemm_set_bf16x3(0)
     for i in range(min(args.warmup, 2)):
         trainer.step(batches[i % len(batches)])
+    F_.PROBE["ffn1_fwd"] = []
     sync_all()
     t3 = time.perf_counter()
     for i in range(args.steps):
         trainer.step(batches[i % len(batches)])
     sync_all()
     elapsed_f = time.perf_counter() - t3
+    probe_f = F_.PROBE.pop("ffn1_fwd")
     _jova_lib().jova_gemm_set_bf16x3(x3_was)
     if dist_on:
         tf_ = torch.tensor([elapsed_f], dtype=torch.float64, device=device)
@@ -503,23 +506,42 @@ def main():
     flops_per_step = float(np.mean([f for f, _ in timed]))
     tokens_per_step = float(np.mean([t for _, t in timed]))
     pairs_per_s = args.steps * bsz * world / elapsed
-    # dominant kernel: the fp32 MFMA GEMM; probe = the FFN linear1 launch (largest single launch of the step)
-    flops = sum(f for _, _, f in probe)
-    ms = sum(a.elapsed_time(b) for a, b, _ in probe)
-    tfl = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    roofline = dict(kernel="gemm_f32_fast_kernel<K-contig,K-contig> (JointAttention FFN linear1, [S*B,512]x[512,2048]+bias+ReLU)",
-                    bound="mfma", achieved=round(tfl, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(tfl / MFMA_F32_PEAK_TFLOPS, 4), traffic=measured_traffic(),
-                    traffic_note="NOT re-measured in this run: bytes per launch of the S=279 launch that "
-                                 "profiles/r02_pmc_ffn1.json profiled (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes; "
-                                 "algorithmic bytes of that launch 369.9e6); this run's launches average S*B = %d tokens"
-                                 % int(tokens_per_step),
-                    launches=len(probe), avg_us=round(ms * 1e3 / max(len(probe), 1), 1))
+    # dominant kernel: the aligned GEMM; probe = the FFN linear1 launch (largest single launch of the step), timed with
+    # HIP events on its stream in both timed regions.  On the fp32 matrix pipe (fp32_mfma_only run) the roofline is the
+    # fp32 MFMA peak over the algorithmic 2 M N K.  In the default run the same product executes as SIX bf16 MFMA products
+    # of three-way split operands: its roofline is the bf16 matrix peak over the 6 x 2 M N K the pipe really executes
+    # (`algorithmic_tflops` = 2 M N K / time, the fp32-equivalent rate, rides along).
+    def probe_stats(pr):
+        fl = sum(f for _, _, f in pr)
+        t_ms = sum(a.elapsed_time(b) for a, b, _ in pr)
+        return fl, t_ms, (fl / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0)
+    flops, ms, tfl = probe_stats(probe)
+    flops_f, ms_f, tfl_f = probe_stats(probe_f)
+    shape_txt = "(JointAttention FFN linear1, [S*B,512]x[512,2048]+bias+ReLU)"
+    traffic_note = ("NOT re-measured in this run: bytes per launch of the S=279 launch that profiles/r02_pmc_ffn1.json "
+                    "profiled on the fp32 MFMA kernel (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes; algorithmic bytes "
+                    "of that launch 369.9e6); this run's launches average S*B = %d tokens" % int(tokens_per_step))
+    roofline_f32 = dict(kernel="gemm_f32_fast_kernel<K-contig,K-contig> " + shape_txt, bound="mfma", achieved=round(tfl_f, 2),
+                        peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tfl_f / MFMA_F32_PEAK_TFLOPS, 4),
+                        traffic=measured_traffic(), traffic_note=traffic_note, launches=len(probe_f),
+                        avg_us=round(ms_f * 1e3 / max(len(probe_f), 1), 1),
+                        note="the probed launch in the fp32_mfma_only run: fp32 MFMA (v_mfma_f32_32x32x2_f32), algorithmic flops")
+    if x3_was >= 2:
+        roofline = dict(kernel="gemm_f32_fast_kernel<K-contig,K-contig,X3: fp32 from bf16 pieces> " + shape_txt, bound="mfma",
+                        achieved=round(6.0 * tfl, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(6.0 * tfl / MFMA_BF16_PEAK_TFLOPS, 4), algorithmic_tflops=round(tfl, 2),
+                        traffic=None, launches=len(probe), avg_us=round(ms * 1e3 / max(len(probe), 1), 1),
+                        note="six v_mfma_f32_32x32x16_bf16 piece products per fp32 product: achieved = 6 x algorithmic "
+                             "flops / time against the dense bf16 matrix peak; algorithmic_tflops = 2MNK / time "
+                             "(fp32-equivalent).  The same launch on the fp32 matrix pipe: roofline_fp32_mfma_only")
+    else:
+        roofline = dict(roofline_f32, achieved=round(tfl, 2), frac=round(tfl / MFMA_F32_PEAK_TFLOPS, 4), launches=len(probe),
+                        avg_us=round(ms * 1e3 / max(len(probe), 1), 1), note="the probed launch in the default run")
     line = dict(metric="DTI training pairs/sec (fwd+bwd, whole node) + achieved HBM GB/s fraction",
                 value=round(pairs_per_s, 1), unit="pairs/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                 ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
                 vs_baseline=None, dtype="f32", data="synthetic",
-                dtype_note="fp32 operands and results everywhere; forward products on fp32 MFMA; backward products (dX, dW) of a GFLOP or more as six bf16 x bf16 piece products of three-way split fp32 operands with fp32 accumulation (error vs fp64 equal to an fp32 FMA chain: tests/test_gpu_ops.py::test_backward_products_from_bf16_pieces_are_fp32_accurate); fp32_mfma_only = the same steps with those products on fp32 MFMA too",
+                dtype_note="fp32 operands and results everywhere; aligned products of a GFLOP or more (forward since round 3, backward dX / dW since round 2) as six bf16 x bf16 piece products of three-way split fp32 operands with fp32 accumulation (error vs fp64 equal to an fp32 FMA chain: tests/test_gpu_ops.py::test_backward_products_from_bf16_pieces_are_fp32_accurate, operand range: ::test_bf16_pieces_operand_range; why the forward is admitted: tests/test_full_size_parity.py::test_reference_fp32_scatter_of_the_joint_attention_stage); fp32_mfma_only = the same steps with every product on fp32 MFMA (bf16x3_mode %d here)" % x3_was,
                 config=dict(workload=workload_text,
                             global_batch=bsz * world, parallelism="dp%d" % world,
                             trainable_params=count_parameters(model)),
@@ -534,6 +556,7 @@ def main():
              "tokens included (no padding mask in the reference); flops = algorithmic, 2 per multiply-add, backward = 2 x "
              "forward (bench.py:step_flops); tflops_per_gpu = flops_per_step / ms_per_step -- with the backward products "
              "on the bf16 pipe this is an fp32-EQUIVALENT rate, the fp32-pipe figure is fp32_mfma_only.tflops_per_gpu")
+    line["roofline_fp32_mfma_only"] = roofline_f32
     line["fp32_mfma_only"] = dict(value=round(args.steps * bsz * world / elapsed_f, 1), unit="pairs/s",
                                   ms_per_step=round(elapsed_f / args.steps * 1e3, 3),
                                   tflops_per_gpu=round(flops_per_step / (elapsed_f / args.steps) / 1e12, 2),

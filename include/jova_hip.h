@@ -127,10 +127,12 @@ int jova_nonsat_fwd(const float* x, int64_t n, float ep, int max_iter, float* ou
 /* spin bound of the barrier above in ticks of the 100 MHz wall clock (0 restores the default, 2 s); process-wide.
  * No counterpart in the reference; tests use it to provoke the give-up path. */
 void jova_nonsat_set_spin_limit(uint64_t ticks);
-/* Backward products of nn.Linear (dX = dY W, dW = dY^T X; torch autograd of proj/dti/train_joint_attn.py:460-466) of a
- * GFLOP or more on aligned shapes run on the bf16 matrix pipe at fp32 accuracy: operands split into three bf16 pieces,
- * six piece products, fp32 accumulation (jova_gemm_f32 / jova_linear_bwd_weight choose it by themselves; forward
- * products never take it).  on = 0 keeps them on the fp32 MFMA kernel, as does JOVA_GEMM_NO_BF16X3 in the environment;
+/* Products of nn.Linear (forward Y = X W^T, and the backward dX = dY W, dW = dY^T X of torch autograd,
+ * proj/dti/train_joint_attn.py:456-466) of a GFLOP or more on aligned shapes run on the bf16 matrix pipe at fp32 accuracy:
+ * every fp32 operand element split into three bf16 pieces, six piece products, fp32 accumulation (jova_gemm_f32 /
+ * jova_linear_bwd_weight choose it by themselves).  mode 0 keeps every product on the fp32 MFMA kernel (as does
+ * JOVA_GEMM_NO_BF16X3 in the environment), 1 = backward products only (JOVA_GEMM_BF16X3_BWD_ONLY; the round-2 rule),
+ * 2 = forward products too (the default since round 3: DESIGN.md section 4 has the evidence from the imported reference);
  * process-wide.  No counterpart in the reference.
  * Operand range of that form: finite operands with |x| <= 3.3895e38 (the largest bfloat16; an fp32 value above it, i.e.
  * within 2^-8 of FLT_MAX, rounds its top piece to infinity and the outputs it feeds are NaN where an fp32 chain stays
@@ -138,8 +140,8 @@ void jova_nonsat_set_spin_limit(uint64_t ticks);
  * range and the product degrades gracefully towards bf16 x 2 accuracy); zeros are exact; a non-finite operand gives NaN
  * (fp32 would give +-inf).  tests/test_gpu_ops.py::test_bf16_pieces_operand_range pins both ends.  Gradients of a
  * training step sit many decades inside this range; data that do not: jova_gemm_set_bf16x3(0). */
-void jova_gemm_set_bf16x3(int on);
-/* the switch's current value (1 = on), the environment default resolved: lets a caller put back what it found */
+void jova_gemm_set_bf16x3(int mode);
+/* the switch's current mode (0 / 1 / 2), the environment default resolved: lets a caller put back what it found */
 int jova_gemm_get_bf16x3(void);
 /* Allocation-free variant of jova_nonsat_fwd.  NO counterpart in the reference: it exists for callers that cannot
  * allocate device memory (code under hipGraph capture, tight serving loops, harnesses that forbid hipMalloc).  Same

@@ -857,11 +857,13 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 
 // backward products on the bf16 matrix pipe (gemm_bf16x3_kernel): -1 = not decided yet (environment), 0 / 1
 static int g_bf16x3 = -1;
+// 0 = every product on the fp32 MFMA kernels, 1 = backward products (dX, dW) on bf16 pieces, 2 = forward products too
 static int bf16x3_state() {
-    if (g_bf16x3 < 0) g_bf16x3 = getenv("JOVA_GEMM_NO_BF16X3") ? 0 : 1;
+    if (g_bf16x3 < 0)
+        g_bf16x3 = getenv("JOVA_GEMM_NO_BF16X3") ? 0 : (getenv("JOVA_GEMM_BF16X3_BWD_ONLY") ? 1 : 2);
     return g_bf16x3;
 }
-extern "C" void jova_gemm_set_bf16x3(int on) { g_bf16x3 = on ? 1 : 0; }
+extern "C" void jova_gemm_set_bf16x3(int mode) { g_bf16x3 = mode <= 0 ? 0 : (mode >= 2 ? 2 : 1); }
 extern "C" int jova_gemm_get_bf16x3(void) { return bf16x3_state(); }
 
 // csum / csum_done: the column sums of A, if the form that runs can add them up on the way (aligned form, A row-contiguous)
@@ -913,9 +915,11 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
     // JOVA_GEMM_NO_BF16X3 keeps everything on the fp32 MFMA kernel.
     static int x3_all = -1;
     if (x3_all < 0) x3_all = getenv("JOVA_GEMM_BF16X3_ALL") ? 1 : 0;              // (measurements: every aligned backward shape)
-    static int x3_fwd = -1;
-    if (x3_fwd < 0) x3_fwd = getenv("JOVA_GEMM_BF16X3_FWD") ? 1 : 0;              // (experiment: forward products too)
     const int x3_env = bf16x3_state();
+    // forward products (both operands K-contiguous) as well: admitted in round 3 on the evidence of
+    // tests/golden/stage_noise_davis_b128.npz (the reference's own fp32 arithmetic with its summation order changed moves
+    // the same downstream gradient by up to 9e-4; this form by 1.2e-4), DESIGN.md section 4
+    const bool x3_fwd = x3_env >= 2;
     static int x3_old = -1;
     if (x3_old < 0) x3_old = getenv("JOVA_GEMM_BF16X3_OLD") ? 1 : 0;              // (A/B: the register-staged kernel)
     const bool x3_want = x3_env && fast_env && nb1 == 1 && nb2 == 1 && (!b_kc || (x3_fwd && a_kc)) && M % 128 == 0 && N % 128 == 0 &&
@@ -1067,9 +1071,15 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
     const long long ts = 32 * Wsel;
     // a lone small product with a long K (the FC head at M = 128): split K over otherwise idle CUs, partial sums
     // added onto a zeroed C (bias comes with split 0; ReLU / residual cannot apply to partial sums)
-    if (splitk == 1 && gz == 1 && !relu && !residual && K >= 256) {
+    static int skt_env = -1, skmin_env = -1;
+    // (targets measured on the thin products of the Davis step, tools/bench_small_gemm.py under a kernel trace: with
+    // 4096 waves / K >= 128 the data gradients of the 194- and 22-wide view projections go from 55.7 / 53.3 to 37.7 /
+    // 29.3 us; 1024 / 256 were the round-2 values)
+    if (skt_env < 0) skt_env = getenv("JOVA_GEMM_SKT") ? atoi(getenv("JOVA_GEMM_SKT")) : 4096;
+    if (skmin_env < 0) skmin_env = getenv("JOVA_GEMM_SKMINK") ? atoi(getenv("JOVA_GEMM_SKMINK")) : 128;
+    if (splitk == 1 && gz == 1 && !relu && !residual && K >= skmin_env) {
         const long long waves = (long long)cdiv(M, ts) * cdiv(N, ts) * Wsel;
-        int sk = (int)(1024 / (waves > 0 ? waves : 1));
+        int sk = (int)(skt_env / (waves > 0 ? waves : 1));
         if (sk > K / 64) sk = K / 64;
         if (sk > 32) sk = 32;
         if (sk >= 2) {

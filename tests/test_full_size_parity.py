@@ -81,19 +81,27 @@ def test_fixture_bounds_are_what_the_docstring_says():
 
 
 def test_reference_fp32_scatter_of_the_joint_attention_stage():
-    """Evidence behind the rule "forward products stay on the fp32 matrix pipe" (VERDICT r02 item 5).
-    stage_noise_davis_b128.npz (tools/make_golden_full.py:gen_stage_noise): the REFERENCE's JointAttention, fp32, run from
-    the double run's stage inputs with eight different summation orders (CPU thread counts 1..8), each compared with the
-    double run.  The gradient w.r.t. the graph view -- the quantity a forward on bf16 pieces moved to 1.17e-4 and a mere
-    re-ordering of fp32 sums (zero-padded view projections) to 1.3e-4 -- stays within 8e-7 in every one of the reference's
-    runs, as it does on the HIP path with fp32 forward products (9e-7): those two variants are 150 x outside the
-    reference's own fp32 scatter for this quantity, so neither is admitted."""
+    """What the REFERENCE's own fp32 arithmetic does to the joint-attention stage when only its summation order changes
+    (stage_noise_davis_b128.npz, tools/make_golden_full.py:gen_stage_noise).  The imported reference's
+    JointAttention runs in fp32 from the double run's stage inputs and upstream gradient and is compared with the double
+    run, (a) with eight CPU thread counts and (b) six times with its latent dimension re-indexed (a permutation applied
+    consistently to every parameter that touches the 512 latent features: the identical function, every contraction over
+    the latent dimension summed in another order).
+      * (a) changes little: torch's CPU GEMM sums in the same order whatever the thread count -- the gradient w.r.t. the
+        graph view stays within 8e-7 of the double run;
+      * (b) is what a different fp32 GEMM does: the stage output moves as in (a) (2e-5), but the gradient w.r.t. the graph
+        view lands anywhere between 7e-7 and 9.1e-4 of its scale (three of six runs above 2.9e-4): one of the 6e7 FFN ReLU
+        masks flips on an influential unit or it does not.
+    So the 1.2e-4 / 1.3e-4 by which a forward on bf16 pieces / a zero-padded view projection moved that gradient in round 2
+    are inside the reference's own fp32 scatter, and the stage-wise GPU test takes its bound for the view gradients from
+    these runs (tests/test_gpu_ops.py::test_davis_full_size_stages_vs_oracle)."""
     z = H.load("stage_noise_davis_b128")
-    assert len(z["threads"]) == 8
-    assert float(z["d_view1"].max()) <= 1e-6 and float(z["d_view0"].max()) <= 1e-6
-    assert 1e-5 <= float(z["ja"].max()) <= 5e-5                      # the stage output itself: 1.6e-5 .. 2.9e-5
-    assert float(z["param_l2"].max()) <= 1e-4                        # whole parameter gradient of the stage: 2e-5 .. 5e-5
-    assert 1.17e-4 / float(z["d_view1"].max()) > 100.0
+    assert len(z["threads"]) == 8 and len(z["perm.d_view1"]) == 6
+    assert float(z["d_view1"].max()) <= 1e-6 and float(z["d_view0"].max()) <= 1e-6           # (a)
+    assert 1e-5 <= float(z["ja"].max()) <= 5e-5 and 1e-5 <= float(z["perm.ja"].max()) <= 5e-5
+    assert float(z["perm.d_view1"].min()) <= 1e-6 and float(z["perm.d_view1"].max()) >= 5e-4  # (b): all or nothing
+    assert int((z["perm.d_view1"] > 1.3e-4).sum()) >= 3
+    assert float(z["perm.d_view0"].max()) <= 1e-5
 
 
 @pytest.mark.parametrize("tag", ["below", "above"])

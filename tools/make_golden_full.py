@@ -340,12 +340,42 @@ def gen_stage_noise(tag="davis_b128", thread_counts=(8, 1, 2, 3, 4, 5, 6, 7)):
         for k, p in net32[1].named_parameters():
             rows.setdefault("g." + k, []).append(rel(p.grad, g64[k]))
     torch.set_num_threads(8)
+    # A second, stronger perturbation of the reference's fp32 rounding: the SAME model with its latent dimension
+    # re-indexed (a permutation of the 512 latent features applied consistently to every parameter that touches them:
+    # rows of the view projections, out_proj and linear2, columns of in_proj and linear1, both LayerNorms, the
+    # BatchNorm behind the view pooling).  Mathematically the identical function; every contraction over the latent
+    # dimension (QKV, FFN linear1 -- the one in front of the 6e7 ReLU masks) is summed in a different order.
+    L_, nv = hp["latent"], len(v64)
+    for seed in range(6):
+        perm = torch.from_numpy(np.random.RandomState(1000 + seed).permutation(L_))
+        idx = torch.cat([v * L_ + perm for v in range(nv)])
+        sdp = {k: v.clone() for k, v in sd.items()}
+        for k in list(sdp):
+            if not k.startswith("1."):
+                continue
+            t = sdp[k]
+            if ".lin_prjs." in k or ".out_proj." in k or k.endswith("seg_lin.linear2.weight") or \
+                    k.endswith("seg_lin.linear2.bias") or ".normalize." in k or ".attn_norm." in k:
+                sdp[k] = t[perm]
+            elif k.endswith("in_proj_weight") or k.endswith("seg_lin.linear1.weight"):
+                sdp[k] = t[:, perm]
+            elif ".batch_norm." in k and t.dim() == 1 and t.numel() == nv * L_:
+                sdp[k] = t[idx]
+        net32 = build_net(hp, pool.protein_profile, views).train()
+        net32.load_state_dict(sdp)
+        v32 = [t.detach().float().requires_grad_(True) for t in v64]
+        ja32 = net32[1](v32)
+        ja32.backward(d_ja64.float()[:, idx])
+        inv = torch.argsort(idx)
+        rows.setdefault("perm.ja", []).append(rel(ja32.detach()[:, inv], ja64.detach()))
+        for i, t in enumerate(v32):
+            rows.setdefault("perm.d_view%d" % i, []).append(rel(t.grad, d_views64[i]))
     arrays = {k: np.array(v) for k, v in rows.items()}
     arrays["threads"] = np.array(thread_counts)
     arrays["spec"] = np.array(json.dumps(dict(tag=tag, pool_seed=pseed, pair_seed=pair_seed, weight_seed=wseed, batch=bsz)))
     np.savez_compressed(os.path.join(MG.OUT, "stage_noise_" + tag + ".npz"), **arrays)
-    for k in ("ja", "d_view0", "d_view1", "d_view2", "param_l2"):
-        print("stage noise %-9s %s" % (k, " ".join("%.2e" % v for v in rows[k])), flush=True)
+    for k in ("ja", "d_view0", "d_view1", "d_view2", "param_l2", "perm.ja", "perm.d_view0", "perm.d_view1", "perm.d_view2"):
+        print("stage noise %-13s %s" % (k, " ".join("%.2e" % v for v in rows[k])), flush=True)
 
 
 if __name__ == "__main__":
