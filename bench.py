@@ -285,11 +285,15 @@ def graph_stress(device, reps=20, full=True, row_order_lines=True):
           4 * (n * 64 + n * 64 + e) + wbytes, launches=1, kernels=("graphconv_fwd_wave_kernel<8, 4, false>",),
           flops=4 * n * 64 * 64)
     order = P(topo.block_order)
-    timed("graphpool_fwd(64)", lambda: call("jova_graphpool_fwd", P(x2), n, 64, ds, adj, P(out), P(arg), order, st),
-          4 * (2 * n * 64 + e) + n * 64, kernels=("graphpool_fwd_v4_kernel",))
-    if row_order_lines:                                    # the same kernel without the XCD-aware block order
+    table = P(topo.row_table)
+    timed("graphpool_fwd(64)", lambda: call("jova_graphpool_fwd", P(x2), n, 64, ds, adj, P(out), P(arg), order, table, st),
+          4 * (2 * n * 64 + e) + n * 64, kernels=("graphpool_fwd_t_kernel",))
+    if row_order_lines:                                    # the same work without the row table / the block order
+        timed("graphpool_fwd(64), no row table",
+              lambda: call("jova_graphpool_fwd", P(x2), n, 64, ds, adj, P(out), P(arg), order, None, st),
+              4 * (2 * n * 64 + e) + n * 64, kernels=("graphpool_fwd_v4_kernel",))
         timed("graphpool_fwd(64), blocks in row order",
-              lambda: call("jova_graphpool_fwd", P(x2), n, 64, ds, adj, P(out), P(arg), None, st),
+              lambda: call("jova_graphpool_fwd", P(x2), n, 64, ds, adj, P(out), P(arg), None, None, st),
               4 * (2 * n * 64 + e) + n * 64, kernels=())
     if full:
         # backward kernels accumulate into gradient buffers (as in the trainer).  In the model the BatchNorm behind
@@ -316,12 +320,16 @@ def graph_stress(device, reps=20, full=True, row_order_lines=True):
               4 * (n * 64 + 3 * n * 64 + e) + 2 * wbytes, launches=3, flops=8 * n * 64 * 64,
               kernels=("graphconv_bwd_wave_kernel<8, true, 2>", "graphconv_bwd_dx_wave_kernel"))
         timed("graphpool_bwd(64)", lambda: call("jova_graphpool_bwd", P(dz), P(arg), n, 64, ds, adj, P(dx),
-                                                P(topo.sym_flag), sym, P(topo.rev_pos), order, st),
-              4 * (2 * n * 64 + e) + n * 64, kernels=("graphpool_bwd_v5_kernel",))
+                                                P(topo.sym_flag), sym, P(topo.rev_pos), order, table, st),
+              4 * (2 * n * 64 + e) + n * 64, kernels=("graphpool_bwd_t_kernel",))
         if row_order_lines:
+            timed("graphpool_bwd(64), no row table",
+                  lambda: call("jova_graphpool_bwd", P(dz), P(arg), n, 64, ds, adj, P(dx), P(topo.sym_flag), sym,
+                               P(topo.rev_pos), order, None, st),
+                  4 * (2 * n * 64 + e) + n * 64, kernels=("graphpool_bwd_v5_kernel",))
             timed("graphpool_bwd(64), blocks in row order",
                   lambda: call("jova_graphpool_bwd", P(dz), P(arg), n, 64, ds, adj, P(dx), P(topo.sym_flag), sym,
-                               P(topo.rev_pos), None, st),
+                               P(topo.rev_pos), None, None, st),
                   4 * (2 * n * 64 + e) + n * 64, kernels=())
     if full:
         # GraphGather2D (contiguous chunks -> zero-padded [A_max, B, g]) and the nonsat activation on it, g = 128

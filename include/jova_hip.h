@@ -75,12 +75,24 @@ int jova_adj_symmetry(int64_t n_atoms, const int64_t* deg_slice, const int32_t* 
  * neighbour's list.
  * block_order (optional, DEVICE int32 [ceil(N/16)], a permutation of the 16-row block numbers; jova_block_order
  * makes it on the host once per batch): which block each workgroup takes, arranged so that an atom's row and its
- * neighbours' reads of it meet in one XCD's L2.  Results do not depend on it; NULL = blocks in row order. */
+ * neighbours' reads of it meet in one XCD's L2.  Results do not depend on it; NULL = blocks in row order.
+ * row_table (optional, DEVICE, from jova_row_table for the SAME block order and adjacency; takes the place of
+ * block_order when given): row, degree, first four neighbours and their reverse positions of every row in launch
+ * order, 32 bytes a row, so the gathers start after one read instead of four dependent ones.  Results do not depend
+ * on it. */
 int jova_graphpool_fwd(const float* x, int64_t n_atoms, int f, const int64_t* deg_slice, const int32_t* const* adj,
-                       float* out, uint8_t* argmax, const int32_t* block_order_or_null, void* stream);
+                       float* out, uint8_t* argmax, const int32_t* block_order_or_null,
+                       const int32_t* row_table_or_null, void* stream);
 int jova_graphpool_bwd(const float* dy, const uint8_t* argmax, int64_t n_atoms, int f, const int64_t* deg_slice,
                        const int32_t* const* adj, float* dx, const int* sym_flag, int host_knows_symmetric,
-                       const uint8_t* rev_pos_or_null, const int32_t* block_order_or_null, void* stream);
+                       const uint8_t* rev_pos_or_null, const int32_t* block_order_or_null,
+                       const int32_t* row_table_or_null, void* stream);
+/* table int32 [16 * ceil(n_atoms/16), 8] (16-byte aligned), slot = launch block * 16 + row in block:
+ * { row or -1, degree, neighbour 0..3 (last one repeated past the degree), rev_pos 0..3 one per byte (0xFF: none), 0 }.
+ * rev_pos NULL: the packed positions are 0xFF (enough for the forward).  No counterpart in the reference: a latency
+ * measure for the gather kernels, built once per batch. */
+int jova_row_table(int64_t n_atoms, const int64_t* deg_slice, const int32_t* const* adj, const uint8_t* rev_pos_or_null,
+                   const int32_t* block_order_or_null, int32_t* table, void* stream);
 /* host-only (no GPU call): order_host receives ceil(n_atoms/16) ints from the HOST copy of deg_slice.  No
  * counterpart in the reference: an MI355X placement hint (8 XCDs, one L2 each). */
 int jova_block_order(const int64_t* deg_slice_host, int64_t n_atoms, int32_t* order_host);
@@ -167,6 +179,25 @@ int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int6
                   int64_t ldc, int M, int N, int K, float alpha, const float* bias, const float* residual, int64_t ldr,
                   int relu, int splitk, int nb1, int nb2, int64_t sA1, int64_t sA2, int64_t sB1, int64_t sB2,
                   int64_t sC1, int64_t sC2, void* stream);
+/* The same product with B split into its bf16 pieces beforehand, once per call instead of once per row tile and wave
+ * (A K-contiguous, B a matrix all row tiles share: the forward products x W^T and the data gradients dY W of the
+ * linear layers; whole 128 x 128 tiles, K % 32 == 0, no batch, no split-K, bf16-pieces mode on for the product).
+ *   jova_gemm_b_image_bytes  size of the image jova_gemm_f32_img would use for this product, 0 when it would run on
+ *                            another form (then the image argument is ignored and may be NULL);
+ *   jova_gemm_b_image        writes the image (DEVICE memory, 16-byte aligned, 6 bytes per element) of B(k, n) =
+ *                            B[k sbk + n sbn]; N % 128 == 0, K % 32 == 0; one small launch on the stream;
+ *   jova_gemm_f32_img        jova_gemm_f32 with that image (NULL: exactly jova_gemm_f32).
+ * Same arithmetic as the in-kernel split (three round-to-nearest pieces, the six products of weight >= 2^-16, fp32
+ * accumulation); only the summation order inside a 32-deep k block differs.  No counterpart in the reference (its
+ * products are torch.nn.Linear, jova/nn/models.py:915-960): a workspace-bringing variant for callers that can hold
+ * 6 N K bytes per product. */
+size_t jova_gemm_b_image_bytes(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, int M,
+                               int N, int K, int nb1, int nb2, int splitk);
+int jova_gemm_b_image(const float* B, int64_t sbk, int64_t sbn, int N, int K, void* image, void* stream);
+int jova_gemm_f32_img(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
+                      int64_t ldc, int M, int N, int K, float alpha, const float* bias, const float* residual,
+                      int64_t ldr, int relu, int splitk, int nb1, int nb2, int64_t sA1, int64_t sA2, int64_t sB1,
+                      int64_t sB2, int64_t sC1, int64_t sC2, const void* b_image_or_null, void* stream);
 
 /* ---- nn.BatchNorm1d (training mode) call sites: proj/dti/train_joint_attn.py:158,163,168,232; models.py:926,972
  * stats fp64 [2,c] from jova_colstats (or from jova_graphconv_fwd's fused epilogue). */

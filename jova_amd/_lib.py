@@ -18,9 +18,10 @@ _SIGS = {
     "jova_graphconv_bwd": "piqqiippp" + "pppp" + "ppppppp",
     "jova_adj_symmetry": "qpppp",
     "jova_collate_gconv": "ippppp" + "i" + "ppppppp" + "pip",
-    "jova_graphpool_fwd": "pqipp" + "pppp",
+    "jova_graphpool_fwd": "pqipp" + "ppppp",
+    "jova_row_table": "qpppppp",
     "jova_block_order": "pqp",
-    "jova_graphpool_bwd": "ppqipp" + "ppippp",
+    "jova_graphpool_bwd": "ppqipp" + "ppipppp",
     "jova_adj_reverse_pos": "qpppp",
     "jova_gather2d_fwd": "ppiiipp",
     "jova_gather2d_bwd": "ppiiipp",
@@ -28,6 +29,8 @@ _SIGS = {
     "jova_nonsat_fwd_noalloc": "pqfippp" + "p",
     "jova_mul": "ppqpp",
     "jova_gemm_f32": "pqqpqqpq" + "iiif" + "ppqii" + "ii" + "qqqqqq" + "p",
+    "jova_gemm_f32_img": "pqqpqqpq" + "iiif" + "ppqii" + "ii" + "qqqqqq" + "pp",
+    "jova_gemm_b_image": "pqqiipp",
     "jova_colstats": "pqipp",
     "jova_batchnorm_fwd": "pqippp" + "ff" + "ppp" + "ippp",
     "jova_batchnorm_bwd": "ppppp" + "qii" + "ppp" + "pp",
@@ -65,7 +68,8 @@ _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "q": ctypes.c_int64, "f": ctypes
 
 EXPORTS = sorted(list(_SIGS) + ["jova_last_error", "jova_abi_version", "jova_nonsat_workspace_bytes",
                                 "jova_graphconv_workspace_floats", "jova_graphconv_bwd_scratch_floats",
-                                "jova_nonsat_set_spin_limit", "jova_nonsat_noalloc_max_n", "jova_gemm_set_bf16x3", "jova_gemm_get_bf16x3"])
+                                "jova_nonsat_set_spin_limit", "jova_nonsat_noalloc_max_n", "jova_gemm_set_bf16x3", "jova_gemm_get_bf16x3",
+                                "jova_gemm_b_image_bytes"])
 
 _lib = None
 
@@ -99,6 +103,8 @@ def lib():
         L.jova_gemm_set_bf16x3.argtypes = [ctypes.c_int]
         L.jova_gemm_get_bf16x3.restype = ctypes.c_int
         L.jova_gemm_get_bf16x3.argtypes = []
+        L.jova_gemm_b_image_bytes.restype = ctypes.c_size_t
+        L.jova_gemm_b_image_bytes.argtypes = [_CT[c] for c in "pqqpqqiiiiii"]
         _lib = L
     return _lib
 

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "jova_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define BK 32
 #define LDS_KC (BK + 1)      // [row][k] image, odd stride: conflict-free ds_read_b32 down a column
@@ -853,6 +854,185 @@ gemm_bf16x3_kernel(X3Args xa) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ bf16 pieces, B split beforehand
+// The bf16-pieces product for a K-contiguous A and a B that many row tiles share (B = a weight matrix: the forward
+// products x W^T and the data gradients dY W of the FFN / projection layers).  PMC passes over the in-kernel form
+// (profiles/r03_pmc_x3_ffn1.json) show its limit: 7.9 VALU instructions per MFMA -- the split of 32 floats per lane and
+// k-tile, every element of A split by both waves that share its rows and every element of B by both waves that share its
+// columns AND by every one of the M / 128 row tiles -- as many VALU cycles as matrix cycles (434 M against 439 M), of which
+// only a quarter overlap.  Here
+//   * B is split ONCE per call by gemm_b_image_kernel into an image of bf16 fragments (6 bytes per element, laid out in
+//     the order the waves read it: [column tile][k32 block][k16 half][piece][32-column block][lane][8 bf16]), which the
+//     workgroups stream into LDS by global_load_lds_dwordx4, 24 KiB per k32 block, three stages, one barrier per block;
+//   * a wave owns 32 rows x 128 columns of the 128 x 128 tile, so its A rows are its own: they come straight from global
+//     memory into registers (64 contiguous bytes per lane and k32 block, requested one block ahead, no LDS, no barrier)
+//     and each element is split once -- 16 floats per lane and k32 block against 64 in the in-kernel form;
+//   * the k order inside a k32 block is permuted (lane half h, half-block s, j < 8: k = 16 h + 8 s + j), the same way for A
+//     and B, which only changes the summation order.
+// Vector memory is inline asm with hand-kept s_waitcnt vmcnt (requests retire in order): at the top of block s the
+// wave needs A(s) and B(s); issued after them is only B(s + 1) (6 requests).
+struct X3WArgs {
+    GemmArgs g;
+    const unsigned char* image;
+    int ntm, ntn, nkb;
+};
+constexpr int X3W_STAGE = 24 * 1024;
+constexpr int X3W_NST = 3;
+
+__global__ void __launch_bounds__(256)
+gemm_b_image_kernel(const float* __restrict__ B, long long sbk, long long sbn, int N, int K, uint4* __restrict__ image) {
+    // one thread per (column, 8 k): unit u = (((nt * nkb + kb) * 2 + s) * 4 + cb) * 64 + lane
+    const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (u >= (long long)N * K / 8) return;
+    const int lane = (int)(u & 63), cb = (int)((u >> 6) & 3), s = (int)((u >> 8) & 1);
+    const long long blk = u >> 9;
+    const int nkb = K / 32;
+    const int kb = (int)(blk % nkb), nt = (int)(blk / nkb);
+    const int n = nt * 128 + cb * 32 + (lane & 31), k = kb * 32 + 16 * (lane >> 5) + 8 * s;
+    float lo[4], hi[4];
+    if (sbk == 1) {
+        const float4 x = *reinterpret_cast<const float4*>(B + (long long)n * sbn + k);
+        const float4 y = *reinterpret_cast<const float4*>(B + (long long)n * sbn + k + 4);
+        lo[0] = x.x; lo[1] = x.y; lo[2] = x.z; lo[3] = x.w;
+        hi[0] = y.x; hi[1] = y.y; hi[2] = y.z; hi[3] = y.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lo[j] = B[(long long)(k + j) * sbk + n];
+            hi[j] = B[(long long)(k + 4 + j) * sbk + n];
+        }
+    }
+    bf16x8_t p[3];
+    split8_regs(lo, hi, p);
+    uint4* dst = image + blk * (X3W_STAGE / 16) + ((s * 3) * 4 + cb) * 64 + lane;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) dst[pc * 4 * 64] = *reinterpret_cast<const uint4*>(&p[pc]);
+}
+
+#define X3W_GLOAD(dst, ptr, off) \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:" #off : "=v"(dst) : "v"(ptr) : "memory")
+
+__global__ void __launch_bounds__(256, 2)
+gemm_x3w_kernel(X3WArgs xa) {
+    __shared__ __attribute__((aligned(16))) unsigned char stages[X3W_NST * X3W_STAGE];
+    const GemmArgs& g = xa.g;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int slot = blockIdx.x;               // workgroups b, b + 8, ... share an XCD: give each XCD a contiguous run of tiles
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = slot & 7, loc = slot >> 3;
+        slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = slot / xa.ntn, nt = slot - mt * xa.ntn;      // column tile fastest: neighbours share their A rows
+    const int m0 = mt * 128 + 32 * wave, n0 = nt * 128;
+    const int nkb = xa.nkb;
+    const float* ap = g.A + (long long)(m0 + i) * g.sam + 16 * h;
+    const unsigned char* bp = xa.image + (long long)nt * nkb * X3W_STAGE + (wave * 6) * 1024 + lane * 16;
+    const unsigned st0 = lds_addr(reinterpret_cast<const float*>(stages)) + (unsigned)(wave * 6) * 1024u;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+
+    f32x4 a0, a1, a2, a3;
+    auto issue_a = [&]() {
+        X3W_GLOAD(a0, ap, 0);
+        X3W_GLOAD(a1, ap, 16);
+        X3W_GLOAD(a2, ap, 32);
+        X3W_GLOAD(a3, ap, 48);
+        ap += 32;
+    };
+    auto issue_b = [&](int stage) {
+        const unsigned dst = st0 + (unsigned)stage * X3W_STAGE;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) dma16(reinterpret_cast<const float*>(bp + p * 1024), dst + p * 1024);
+        bp += X3W_STAGE;
+    };
+    issue_a();
+    issue_b(0);
+    if (nkb > 1) issue_b(1);
+
+    int cur = 0, refill = 2;
+    // The registers the asm loads write must be the ones the split reads, with no copy in between that could run
+    // before the wait: the wait only READS a0..a3 (no new definition to allocate), scheduling barriers pin the split
+    // between the wait and the next loads (so the old and the new values never live together and the loop-carried
+    // value stays in place), and the last block is a second copy of the body (one wait statement per copy).
+    auto block = [&](int s, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        if (!LAST) asm volatile("s_waitcnt vmcnt(6)" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8_t pa[2][3];
+        {
+            const float l0[4] = {a0[0], a0[1], a0[2], a0[3]}, h0[4] = {a1[0], a1[1], a1[2], a1[3]};
+            const float l1[4] = {a2[0], a2[1], a2[2], a2[3]}, h1[4] = {a3[0], a3[1], a3[2], a3[3]};
+            split8_regs(l0, h0, pa[0]);
+            split8_regs(l1, h1, pa[1]);
+        }
+        // (the pieces are complete here: an empty asm that "rewrites" them keeps the split from sinking below the loads)
+        asm volatile("" : "+v"(pa[0][0]), "+v"(pa[0][1]), "+v"(pa[0][2]), "+v"(pa[1][0]), "+v"(pa[1][1]), "+v"(pa[1][2])::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();    // B(s) of every wave has landed; every wave is past its reads of stage `refill`
+        asm volatile("" ::: "memory");
+        if (!LAST) issue_a();
+        if (!LAST && s + 2 < nkb) issue_b(refill);
+        const unsigned char* sb = stages + cur * X3W_STAGE + lane * 16;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8_t bf[4];
+            // small terms first: A.h B.l | A.m B.m, A.h B.m | A.l B.h, A.m B.h, A.h B.h
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) bf[cb] = *reinterpret_cast<const bf16x8_t*>(sb + ((s2 * 3 + 2) * 4 + cb) * 1024);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2][0], bf[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) bf[cb] = *reinterpret_cast<const bf16x8_t*>(sb + ((s2 * 3 + 1) * 4 + cb) * 1024);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2][1], bf[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2][0], bf[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) bf[cb] = *reinterpret_cast<const bf16x8_t*>(sb + ((s2 * 3 + 0) * 4 + cb) * 1024);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2][2], bf[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2][1], bf[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2][0], bf[cb], acc[cb], 0, 0, 0);
+        }
+        cur = cur == X3W_NST - 1 ? 0 : cur + 1;
+        refill = refill == X3W_NST - 1 ? 0 : refill + 1;
+    };
+    for (int s = 0; s + 1 < nkb; ++s) block(s, std::false_type());
+    block(nkb - 1, std::true_type());
+
+    // epilogue: alpha, bias, residual / ReLU mask, ReLU (as the whole-tile branch of gemm_f32_fast_kernel)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int n = n0 + 32 * cb + i;
+        const float bias = g.bias ? g.bias[n] : 0.f;
+        float* crow = g.C + n;
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + mfma32_row(r, lane);
+            rv[r] = g.R ? g.R[(long long)m * g.ldr + n] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + mfma32_row(r, lane);
+            float v = g.alpha * acc[cb][r] + bias;
+            if (g.relu == 2) v = rv[r] > 0.f ? v : 0.f;
+            else v += rv[r];
+            if (g.relu == 1) v = fmaxf(v, 0.f);
+            crow[(long long)m * g.ldc] = v;
+        }
+    }
+}
+#undef X3W_GLOAD
+
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // backward products on the bf16 matrix pipe (gemm_bf16x3_kernel): -1 = not decided yet (environment), 0 / 1
@@ -871,11 +1051,12 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
                      float* C, int64_t ldc, int M, int N, int K, float alpha, const float* bias,
                      const float* residual, int64_t ldr, int relu, int splitk, int nb1, int nb2, int64_t sA1,
                      int64_t sA2, int64_t sB1, int64_t sB2, int64_t sC1, int64_t sC2, void* stream, float* csum,
-                     bool* csum_done) {
+                     bool* csum_done, const void* b_image = nullptr, size_t* b_image_bytes_query = nullptr) {
     if (csum_done) *csum_done = false;
+    if (b_image_bytes_query) *b_image_bytes_query = 0;
     JOVA_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && nb1 >= 1 && nb2 >= 1, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
     if (M == 0 || N == 0) return JOVA_OK;                    // (an empty product: pointers of empty tensors are null)
-    JOVA_CHECK_ARG(A && B && C, "gemm: null pointer");
+    JOVA_CHECK_ARG(A && B && (C || b_image_bytes_query), "gemm: null pointer");
     JOVA_CHECK_ARG(sam == 1 || sak == 1, "gemm: A needs a unit stride (sam=%lld sak=%lld)", (long long)sam, (long long)sak);
     JOVA_CHECK_ARG(sbk == 1 || sbn == 1, "gemm: B needs a unit stride (sbk=%lld sbn=%lld)", (long long)sbk, (long long)sbn);
     JOVA_CHECK_ARG(splitk >= 1 && (splitk == 1 || (!residual && !relu)), "gemm: split-K excludes residual/relu");
@@ -925,6 +1106,29 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
     const bool x3_want = x3_env && fast_env && nb1 == 1 && nb2 == 1 && (!b_kc || (x3_fwd && a_kc)) && M % 128 == 0 && N % 128 == 0 &&
                          K % XBK == 0 && K > 0 && va && vb && (x3_all || (long long)M * N * K >= (1ll << 30)) &&
                          (splitk == 1 || ldc == N);
+    // A K-contiguous, B a matrix every row tile shares (forward products and data gradients of the linear layers), whole
+    // tiles: B split beforehand into the caller's image, A split once per element (gemm_x3w_kernel)
+    static int x3w_env = -1;
+    if (x3w_env < 0) x3w_env = getenv("JOVA_GEMM_NO_X3W") ? 0 : 1;
+    const bool x3w = x3_want && x3w_env && a_kc && splitk == 1 && !x3_old && (long long)N * K * 6 < (1ll << 31);
+    if (b_image_bytes_query) {
+        *b_image_bytes_query = x3w ? (size_t)N * K * 6 : 0;
+        return JOVA_OK;
+    }
+    if (x3w && b_image) {
+        JOVA_CHECK_ARG(aligned16(b_image), "gemm: the B image must be 16-byte aligned");
+        X3WArgs xw;
+        xw.g = g;
+        xw.image = (const unsigned char*)b_image;
+        xw.ntm = M / 128;
+        xw.ntn = N / 128;
+        xw.nkb = K / 32;
+        const long long nwg = (long long)xw.ntm * xw.ntn;
+        JOVA_CHECK_ARG(nwg < (1ll << 31), "gemm: too many tiles");
+        hipLaunchKernelGGL(gemm_x3w_kernel, dim3((unsigned)nwg), dim3(256), 0, s, xw);
+        JOVA_CHECK_LAUNCH("gemm_x3w");
+        return JOVA_OK;
+    }
     // dW (both operands row-contiguous) on the register-staged kernel (262-290 us against 292-332 us), dX (A K-contiguous)
     // on the LDS-DMA form of the persistent kernel (338 us against 364 us on average): kernel trace of the Davis step
     if (x3_want && (x3_old || !a_kc)) {
@@ -1127,6 +1331,41 @@ extern "C" int jova_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
                              int64_t sA2, int64_t sB1, int64_t sB2, int64_t sC1, int64_t sC2, void* stream) {
     return gemm_impl(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha, bias, residual, ldr, relu, splitk, nb1, nb2, sA1,
                      sA2, sB1, sB2, sC1, sC2, stream, nullptr, nullptr);
+}
+
+// The same product with B split beforehand (see gemm_x3w_kernel).  jova_gemm_b_image_bytes: the size of the image this
+// product would use -- 0 when it would not run on that form (shape, alignment, mode), in which case jova_gemm_f32_img
+// ignores the image.  jova_gemm_b_image writes the image of B(k, n) = B[k sbk + n sbn], N % 128 == 0, K % 32 == 0.
+extern "C" size_t jova_gemm_b_image_bytes(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
+                                          int64_t sbn, int M, int N, int K, int nb1, int nb2, int splitk) {
+    size_t need = 0;
+    if (!A || !B || M <= 0 || N <= 0 || K <= 0 || nb1 < 1 || nb2 < 1 || splitk < 1 || (sam != 1 && sak != 1) ||
+        (sbk != 1 && sbn != 1))
+        return 0;
+    const int rc = gemm_impl(A, sam, sak, B, sbk, sbn, nullptr, N, M, N, K, 1.f, nullptr, nullptr, 0, 0, splitk, nb1, nb2, 0,
+                             0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, &need);
+    return rc == JOVA_OK ? need : 0;
+}
+
+extern "C" int jova_gemm_b_image(const float* B, int64_t sbk, int64_t sbn, int N, int K, void* image, void* stream) {
+    JOVA_CHECK_ARG(B && image && N > 0 && K > 0 && N % 128 == 0 && K % 32 == 0, "gemm_b_image: bad argument");
+    JOVA_CHECK_ARG((sbk == 1 && sbn % 4 == 0 && aligned16(B)) || (sbn == 1 && sbk >= N),
+                   "gemm_b_image: B needs a unit stride (and 16-byte aligned rows when K-contiguous)");
+    JOVA_CHECK_ARG(aligned16(image) && (long long)N * K * 6 < (1ll << 31), "gemm_b_image: image misaligned or too large");
+    const long long units = (long long)N * K / 8;
+    hipLaunchKernelGGL(gemm_b_image_kernel, dim3((unsigned)cdiv(units, 256)), dim3(256), 0, (hipStream_t)stream, B,
+                       (long long)sbk, (long long)sbn, N, K, (uint4*)image);
+    JOVA_CHECK_LAUNCH("gemm_b_image");
+    return JOVA_OK;
+}
+
+extern "C" int jova_gemm_f32_img(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+                                 float* C, int64_t ldc, int M, int N, int K, float alpha, const float* bias,
+                                 const float* residual, int64_t ldr, int relu, int splitk, int nb1, int nb2, int64_t sA1,
+                                 int64_t sA2, int64_t sB1, int64_t sB2, int64_t sC1, int64_t sC2,
+                                 const void* b_image_or_null, void* stream) {
+    return gemm_impl(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha, bias, residual, ldr, relu, splitk, nb1, nb2, sA1,
+                     sA2, sB1, sB2, sC1, sC2, stream, nullptr, nullptr, b_image_or_null, nullptr);
 }
 
 // dw[n_out, k_in] += dy[rows, n_out]^T x[rows, k_in];  db[n_out] += column sums of dy  (the two gradients of an nn.Linear).

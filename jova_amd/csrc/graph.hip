@@ -1576,6 +1576,155 @@ graphpool_bwd_v5_kernel(const float* __restrict__ dy, const unsigned char* __res
     }
 }
 
+// Row table (optional, made once per batch by jova_row_table): slot = launch block * 16 + row-in-block holds
+//   { row | -1, degree, the first four neighbours, their four reverse positions packed one per byte, 0 }
+// so a 16-lane group starts its gathers after ONE 32-byte read instead of after the chain block order -> degree
+// buckets -> adjacency pointer -> adjacency row (four dependent round trips that left the pool kernels latency-bound).
+// Neighbours five and up (rare: degree > 4) are read from the adjacency lists as before.
+__global__ void __launch_bounds__(256)
+row_table_kernel(int n_atoms, int n_slots, const long long* __restrict__ deg_slice, GcParams P,
+                 const unsigned char* __restrict__ rev_pos, const int* __restrict__ order, int n_blocks,
+                 int4* __restrict__ table) {
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= n_slots) return;
+    const int b = slot >> 4;
+    const int blk = order ? min(max(order[b], 0), n_blocks - 1) : b;
+    const long long row = (long long)blk * 16 + (slot & 15);
+    int4 t0 = make_int4(-1, 0, 0, 0), t1 = make_int4(0, 0, (int)0xFFFFFFFFu, 0);
+    if (row < n_atoms) {
+        int deg;
+        long long lrow, eoff;
+        find_bucket_off(deg_slice, row, deg, lrow, eoff);
+        int j[4] = {0, 0, 0, 0};
+        unsigned pk = 0xFFFFFFFFu;
+        if (deg > 0) {
+            const int* arow = P.adj[deg - 1] + lrow * deg;
+            pk = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int nn = min(u, deg - 1);
+                j[u] = min(max(arow[nn], 0), n_atoms - 1);
+                const unsigned p = (u < deg && rev_pos) ? (unsigned)rev_pos[eoff + nn] : 0xFFu;
+                pk |= p << (8 * u);
+            }
+        }
+        t0 = make_int4((int)row, deg, j[0], j[1]);
+        t1 = make_int4(j[2], j[3], (int)pk, 0);
+    }
+    table[2 * (long long)slot] = t0;
+    table[2 * (long long)slot + 1] = t1;
+}
+
+__global__ void __launch_bounds__(256)
+graphpool_fwd_t_kernel(const float* __restrict__ x, int n_atoms, int f, const long long* __restrict__ deg_slice,
+                       GcParams P, float* __restrict__ out, unsigned char* __restrict__ arg,
+                       const int4* __restrict__ table) {
+    const int l16 = threadIdx.x & 15;
+    const long long slot = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int4 t0 = table[2 * slot], t1 = table[2 * slot + 1];
+    const long long row = t0.x;
+    if (row < 0 || row >= n_atoms) return;
+    const int deg = min(max(t0.y, 0), 10);
+    const int j0[4] = {min(max(t0.z, 0), n_atoms - 1), min(max(t0.w, 0), n_atoms - 1), min(max(t1.x, 0), n_atoms - 1),
+                       min(max(t1.y, 0), n_atoms - 1)};
+    const int* arow = nullptr;
+    if (deg > 4) {
+        int d2;
+        long long lrow;
+        find_bucket(deg_slice, row, d2, lrow);
+        arow = P.adj[deg - 1] + lrow * deg;
+    }
+    for (int c = 4 * l16; c < f; c += 64) {
+        float4 best = *reinterpret_cast<const float4*>(x + row * f + c);
+        int ax = 0, ay = 0, az = 0, aw = 0;
+        for (int n = 0; n < deg; n += 4) {
+            int j[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                j[u] = n == 0 ? j0[u] : min(max(arow[min(n + u, deg - 1)], 0), n_atoms - 1);
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + (long long)j[u] * f + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (n + u < deg) {
+                    if (v[u].x > best.x) { best.x = v[u].x; ax = n + u + 1; }
+                    if (v[u].y > best.y) { best.y = v[u].y; ay = n + u + 1; }
+                    if (v[u].z > best.z) { best.z = v[u].z; az = n + u + 1; }
+                    if (v[u].w > best.w) { best.w = v[u].w; aw = n + u + 1; }
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(out + row * f + c) = best;
+        *reinterpret_cast<unsigned*>(arg + row * f + c) = (unsigned)ax | ((unsigned)ay << 8) | ((unsigned)az << 16) |
+                                                          ((unsigned)aw << 24);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+graphpool_bwd_t_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg, int n_atoms, int f,
+                       const long long* __restrict__ deg_slice, GcParams P,
+                       const unsigned char* __restrict__ rev_pos, float* __restrict__ dx,
+                       const int4* __restrict__ table) {
+    const int l16 = threadIdx.x & 15;
+    const long long slot = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int4 t0 = table[2 * slot], t1 = table[2 * slot + 1];
+    const long long row = t0.x;
+    if (row < 0 || row >= n_atoms) return;
+    const int deg = min(max(t0.y, 0), 10);
+    const long long j0[4] = {min(max(t0.z, 0), n_atoms - 1), min(max(t0.w, 0), n_atoms - 1),
+                             min(max(t1.x, 0), n_atoms - 1), min(max(t1.y, 0), n_atoms - 1)};
+    const unsigned pk = (unsigned)t1.z;
+    const int* arow = nullptr;
+    const unsigned char* prow = nullptr;
+    if (deg > 4) {
+        int d2;
+        long long lrow, eoff;
+        find_bucket_off(deg_slice, row, d2, lrow, eoff);
+        arow = P.adj[deg - 1] + lrow * deg;
+        prow = rev_pos + eoff;
+    }
+    for (int c = 4 * l16; c < f; c += 64) {
+        const unsigned a0 = *reinterpret_cast<const unsigned*>(arg + row * f + c);
+        const float4 g0 = *reinterpret_cast<const float4*>(dy + row * f + c);
+        float4 s;
+        s.x = (a0 & 0xFF) == 0 ? g0.x : 0.f;
+        s.y = ((a0 >> 8) & 0xFF) == 0 ? g0.y : 0.f;
+        s.z = ((a0 >> 16) & 0xFF) == 0 ? g0.z : 0.f;
+        s.w = (a0 >> 24) == 0 ? g0.w : 0.f;
+        for (int n = 0; n < deg; n += 4) {
+            long long j[4];
+            unsigned p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (n == 0) {
+                    j[u] = j0[u];
+                    p[u] = u < deg ? (pk >> (8 * u)) & 0xFFu : 0x100u;      // 0x100 matches no arg-max code
+                } else {
+                    const int nn = min(n + u, deg - 1);
+                    j[u] = min(max(arow[nn], 0), n_atoms - 1);
+                    p[u] = n + u < deg ? (unsigned)prow[nn] : 0x100u;
+                }
+            }
+            unsigned a[4];
+            float4 g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = *reinterpret_cast<const unsigned*>(arg + j[u] * f + c);
+                g[u] = *reinterpret_cast<const float4*>(dy + j[u] * f + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s.x += (a[u] & 0xFF) == p[u] ? g[u].x : 0.f;
+                s.y += ((a[u] >> 8) & 0xFF) == p[u] ? g[u].y : 0.f;
+                s.z += ((a[u] >> 16) & 0xFF) == p[u] ? g[u].z : 0.f;
+                s.w += (a[u] >> 24) == p[u] ? g[u].w : 0.f;
+            }
+        }
+        *reinterpret_cast<float4*>(dx + row * f + c) = s;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 graphconv_bwd_dx_v4_kernel(int n_atoms, int f, const long long* __restrict__ deg_slice, GcParams P,
                            const float* __restrict__ gbuf, float* __restrict__ dx, const int* __restrict__ sym_flag,
@@ -3121,15 +3270,19 @@ graphconv_bwd_dx_wave_kernel(const float* __restrict__ dz, int n_atoms, GcParams
     };
     const int np = *sym_flag != 0 ? deg : 0;
     // indices of a tile in the gather layout: lane -> atom 4 j + q (j = 0..3), 16-byte chunk i of its row
-    unsigned nb0[4], nb1[4];
+    // (list positions 0..3 are all requested a tile ahead: a degree-3 or -4 tile, the common case of a bond graph,
+    // starts its second pair of gathers without another index round trip)
+    unsigned nb0[4], nb1[4], nb2[4], nb3[4];
     auto load_nb = [&](int t) {
         const int lrow0 = t * WT, rows = min(WT, bsize - lrow0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int lr = lrow0 + min(4 * j + q, rows - 1);
-            nb0[j] = nb1[j] = 0;
+            nb0[j] = nb1[j] = nb2[j] = nb3[j] = 0;
             if (np > 0) nb0[j] = (unsigned)adj_d[(unsigned)(lr * deg)];
             if (np > 1) nb1[j] = (unsigned)adj_d[(unsigned)(lr * deg + 1)];
+            if (np > 2) nb2[j] = (unsigned)adj_d[(unsigned)(lr * deg + 2)];
+            if (np > 3) nb3[j] = (unsigned)adj_d[(unsigned)(lr * deg + 3)];
         }
     };
     // the wave's first dZ tile and its first indices travel while the weights are staged
@@ -3206,10 +3359,18 @@ graphconv_bwd_dx_wave_kernel(const float* __restrict__ dz, int n_atoms, GcParams
         for (int j = 0; j < 4; ++j) o[j] += g0[j] + g1[j];
         for (int p = 2; p < np; p += 2) {                          // further neighbours, two rows in flight
             const bool two = p + 1 < np;
+            if (p == 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                nb0[j] = (unsigned)adj_d[(unsigned)(lr[j] * deg + p)];
-                nb1[j] = two ? (unsigned)adj_d[(unsigned)(lr[j] * deg + p + 1)] : nb0[j];
+                for (int j = 0; j < 4; ++j) {
+                    nb0[j] = nb2[j];
+                    nb1[j] = two ? nb3[j] : nb2[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    nb0[j] = (unsigned)adj_d[(unsigned)(lr[j] * deg + p)];
+                    nb1[j] = two ? (unsigned)adj_d[(unsigned)(lr[j] * deg + p + 1)] : nb0[j];
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -3676,6 +3837,26 @@ extern "C" int jova_adj_reverse_pos(int64_t n_atoms, const int64_t* deg_slice, c
     return JOVA_OK;
 }
 
+// The row table of the gather kernels (see row_table_kernel): 8 ints per slot, 16 * ceil(n_atoms/16) slots, in the
+// launch order block_order gives (identity when null).  rev_pos may be null (the packed positions are then 0xFF: the
+// table still serves GraphPool's forward).
+extern "C" int jova_row_table(int64_t n_atoms, const int64_t* deg_slice, const int32_t* const* adj,
+                              const uint8_t* rev_pos_or_null, const int32_t* block_order_or_null, int32_t* table,
+                              void* stream) {
+    JOVA_CHECK_ARG(deg_slice && adj && (n_atoms == 0 || table), "row_table: null pointer");
+    JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 27), "row_table: n_atoms out of range");
+    JOVA_CHECK_ARG((((uintptr_t)table) & 15) == 0, "row_table: table must be 16-byte aligned");
+    if (n_atoms == 0) return JOVA_OK;
+    GcParams P;
+    fill_params(P, adj, nullptr, nullptr);
+    const int n_blocks = (int)cdiv(n_atoms, 16), n_slots = n_blocks * 16;
+    hipLaunchKernelGGL(row_table_kernel, dim3(cdiv(n_slots, 256)), dim3(256), 0, (hipStream_t)stream, (int)n_atoms,
+                       n_slots, (const long long*)deg_slice, P, rev_pos_or_null, block_order_or_null, n_blocks,
+                       (int4*)table);
+    JOVA_CHECK_LAUNCH("row_table");
+    return JOVA_OK;
+}
+
 // Host-side: the XCD-aware order of the 16-row blocks (see ordered_block).  order_host receives ceil(n_atoms/16) ints,
 // a permutation of the block numbers.
 extern "C" int jova_block_order(const int64_t* deg_slice_host, int64_t n_atoms, int32_t* order_host) {
@@ -3705,13 +3886,18 @@ extern "C" int jova_block_order(const int64_t* deg_slice_host, int64_t n_atoms, 
 
 extern "C" int jova_graphpool_fwd(const float* x, int64_t n_atoms, int f, const int64_t* deg_slice,
                                   const int32_t* const* adj, float* out, uint8_t* argmax,
-                                  const int32_t* block_order_or_null, void* stream) {
+                                  const int32_t* block_order_or_null, const int32_t* row_table_or_null, void* stream) {
     JOVA_CHECK_ARG(deg_slice && adj && (n_atoms == 0 || (x && out && argmax)), "graphpool_fwd: null pointer");
     JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 31) && f >= 1, "graphpool_fwd: bad shape");
     if (n_atoms == 0) return JOVA_OK;
     GcParams P;
     fill_params(P, adj, nullptr, nullptr);
-    if ((f & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)out) | ((uintptr_t)argmax)) & 15) == 0)
+    const bool vec = (f & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)out) | ((uintptr_t)argmax)) & 15) == 0;
+    if (vec && row_table_or_null && (((uintptr_t)row_table_or_null) & 15) == 0)
+        hipLaunchKernelGGL(graphpool_fwd_t_kernel, dim3(cdiv(n_atoms, 16)), dim3(256), 0, (hipStream_t)stream, x,
+                           (int)n_atoms, f, (const long long*)deg_slice, P, out, argmax,
+                           (const int4*)row_table_or_null);
+    else if (vec)
         hipLaunchKernelGGL(graphpool_fwd_v4_kernel, dim3(cdiv(n_atoms, 16)), dim3(256), 0, (hipStream_t)stream, x,
                            (int)n_atoms, f, (const long long*)deg_slice, P, out, argmax, block_order_or_null);
     else
@@ -3724,7 +3910,7 @@ extern "C" int jova_graphpool_fwd(const float* x, int64_t n_atoms, int f, const 
 extern "C" int jova_graphpool_bwd(const float* dy, const uint8_t* argmax, int64_t n_atoms, int f,
                                   const int64_t* deg_slice, const int32_t* const* adj, float* dx, const int* sym_flag,
                                   int sym_flag_host_hint, const uint8_t* rev_pos_or_null,
-                                  const int32_t* block_order_or_null, void* stream) {
+                                  const int32_t* block_order_or_null, const int32_t* row_table_or_null, void* stream) {
     JOVA_CHECK_ARG(deg_slice && adj && (n_atoms == 0 || (dy && argmax && dx)), "graphpool_bwd: null pointer");
     JOVA_CHECK_ARG(n_atoms >= 0 && n_atoms < (1ll << 31) && f >= 1, "graphpool_bwd: bad shape");
     if (n_atoms == 0) return JOVA_OK;
@@ -3733,6 +3919,13 @@ extern "C" int jova_graphpool_bwd(const float* dy, const uint8_t* argmax, int64_
     fill_params(P, adj, nullptr, nullptr);
     // the caller may vouch for a symmetric adjacency (it read the flag once per batch): 16-lanes-per-row gather form
     if (sym_flag_host_hint == 1 && (f & 3) == 0 && ((((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)argmax)) & 15) == 0) {
+        if (rev_pos_or_null && row_table_or_null && (((uintptr_t)row_table_or_null) & 15) == 0) {
+            hipLaunchKernelGGL(graphpool_bwd_t_kernel, dim3(cdiv(n_atoms, 16)), dim3(256), 0, s, dy, argmax,
+                               (int)n_atoms, f, (const long long*)deg_slice, P, rev_pos_or_null, dx,
+                               (const int4*)row_table_or_null);
+            JOVA_CHECK_LAUNCH("graphpool_bwd_t");
+            return JOVA_OK;
+        }
         if (rev_pos_or_null) {
             hipLaunchKernelGGL(graphpool_bwd_v5_kernel, dim3(cdiv(n_atoms, 16)), dim3(256), 0, s, dy, argmax,
                                (int)n_atoms, f, (const long long*)deg_slice, P, rev_pos_or_null, dx,

@@ -112,6 +112,7 @@ class Topology(object):
         self._deg_slice_host = None
         self._rev_pos = None
         self._block_order = None
+        self._row_table = None
 
     def atoms_f32(self, atoms):
         """fp32 copy of the batch's int64 atom features, rows zero-padded to a multiple of 16 floats (made once)."""
@@ -145,6 +146,17 @@ class Topology(object):
                  ctypes.c_void_p(host.ctypes.data))
             self._block_order = torch.from_numpy(host).to(self.deg_slice.device)
         return self._block_order
+
+    @property
+    def row_table(self):
+        """jova_row_table of the batch (once per batch): row, degree, first four neighbours and reverse positions of
+        every row in launch order, so the pool kernels start gathering after one read."""
+        if self._row_table is None and self.n_atoms:
+            n_blocks = (self.n_atoms + 15) // 16
+            self._row_table = torch.empty((n_blocks * 16, 8), dtype=torch.int32, device=self.deg_slice.device)
+            call("jova_row_table", self.n_atoms, P(self.deg_slice), self.adj_ptrs, P(self.rev_pos),
+                 P(self.block_order), P(self._row_table), stream())
+        return self._row_table
 
     @property
     def deg_slice_host(self):
@@ -243,7 +255,7 @@ class GraphPoolFunction(torch.autograd.Function):
         out = _empty((n, f), atoms)
         arg = _empty((n, f), atoms, torch.uint8)
         call("jova_graphpool_fwd", P(atoms), n, f, P(topo.deg_slice), topo.adj_ptrs, P(out), P(arg),
-             P(topo.block_order) if n else None, stream())
+             P(topo.block_order) if n else None, P(topo.row_table) if n else None, stream())
         ctx.topo = topo
         ctx.save_for_backward(arg)
         return out
@@ -256,7 +268,8 @@ class GraphPoolFunction(torch.autograd.Function):
         n, f = dy.shape
         dx = _empty((n, f), dy)
         call("jova_graphpool_bwd", P(dy), P(arg), n, f, P(topo.deg_slice), topo.adj_ptrs, P(dx), P(topo.sym_flag),
-             int(topo.symmetric), P(topo.rev_pos), P(topo.block_order) if n else None, stream())
+             int(topo.symmetric), P(topo.rev_pos), P(topo.block_order) if n else None,
+             P(topo.row_table) if n else None, stream())
         return dx, None
 
 
@@ -329,17 +342,38 @@ PROBE = {}      # tag -> list of (start event, end event, flops): bench.py times
 
 
 def gemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha=1.0, bias=None, residual=None, ldr=0, relu=False, splitk=1,
-         nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), tag=None):
+         nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), tag=None, _img=None):
     """Thin wrapper over jova_gemm_f32; A, B, C, bias, residual are ctypes addresses (see _addr)."""
+    img = _img
+    if img is None and nb1 == 1 and nb2 == 1:
+        img = _b_image(A, sam, sak, B, sbk, sbn, M, N, K, splitk)          # (outside the probe's events: its own launch)
     if tag is not None and tag in PROBE:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        gemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha, bias, residual, ldr, relu, splitk, nb1, nb2, sA, sB, sC)
+        gemm(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha, bias, residual, ldr, relu, splitk, nb1, nb2, sA, sB, sC,
+             _img=img)
         e1.record()
         PROBE[tag].append((e0, e1, 2.0 * M * N * K * nb1 * nb2))
         return
+    if img is not None:
+        call("jova_gemm_f32_img", A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, float(alpha), bias, residual, ldr, int(relu),
+             splitk, nb1, nb2, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], P(img), stream())
+        return
     call("jova_gemm_f32", A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, float(alpha), bias, residual, ldr, int(relu),
          splitk, nb1, nb2, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], stream())
+
+
+def _b_image(A, sam, sak, B, sbk, sbn, M, N, K, splitk=1):
+    """The bf16-pieces image of B for a product of a GFLOP or more that jova_gemm_f32_img would run with it (None
+    otherwise): one small launch, 6 N K bytes from torch's caching allocator."""
+    if M * N * K < (1 << 30) or sak != 1:
+        return None
+    need = _lib.lib().jova_gemm_b_image_bytes(A, sam, sak, B, sbk, sbn, M, N, K, 1, 1, splitk)
+    if not need:
+        return None
+    img = torch.empty(need, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+    call("jova_gemm_b_image", B, sbk, sbn, N, K, P(img), stream())
+    return img
 
 
 def linear_fwd(x2d, w, b, out2d, relu=False, residual=None, tag=None):

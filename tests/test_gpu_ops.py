@@ -437,6 +437,49 @@ def test_graphpool_ties_vs_reference_golden(device):
     H.assert_close(x.grad, z["gx"], tol=1e-6, what="dx (tie routing: first maximal index, self first)")
 
 
+def test_graphpool_all_degrees_with_and_without_the_row_table(device):
+    """GraphPool forward + backward on a batch that populates every degree bucket 0..10 (the row table holds four
+    neighbours: atoms of degree 5..10 read the rest from the adjacency lists) against the oracle, and bit-equal between
+    the table form (what the module runs) and the forms without it."""
+    from jova_amd import synth
+    from jova_amd.nn import functional as F_
+    from jova_amd.nn.layers import GraphPool
+    from oracle import nn_ref as R
+    rng = np.random.RandomState(65)
+    mols = [synth.make_molecule(rng, int(n), deg_cap=4, hub_frac=0.15) for n in rng.randint(14, 60, size=150)]
+    mols.append(synth.make_molecule(rng, 1))
+    gl_cpu = H.oracle_glist(mols)
+    n = gl_cpu[0].shape[0]
+    assert all(int(a.shape[0]) > 0 for a in gl_cpu[4:]) and int(gl_cpu[1][0, 1]) > 0, "buckets 0..10 populated"
+    torch.manual_seed(9)
+    x = torch.randn(n, 64).round(decimals=1)                      # coarse values: plenty of ties
+    gout = torch.randn(n, 64)
+    xo = x.double().requires_grad_(True)
+    ref = R.graph_pool(xo, gl_cpu[1], gl_cpu[4:])
+    (ref * gout.double()).sum().backward()
+    xd = x.to(device).requires_grad_(True)
+    gl = _glist_dev(mols, device, xd)
+    out = GraphPool()(gl)
+    (out * gout.to(device)).sum().backward()
+    assert torch.equal(out.detach().cpu(), ref.detach().float())
+    H.assert_close(xd.grad, xo.grad.float(), tol=1e-6, what="dx")
+    topo = gl[1]._jova_topology
+    assert topo.symmetric and topo.row_table is not None and int((topo.row_table[:, 1] > 4).sum()) > 0
+    o2, a1, a2 = torch.empty_like(out), torch.empty(n, 64, dtype=torch.uint8, device=device), \
+        torch.empty(n, 64, dtype=torch.uint8, device=device)
+    F_.call("jova_graphpool_fwd", F_.P(xd.detach()), n, 64, F_.P(topo.deg_slice), topo.adj_ptrs, F_.P(o2), F_.P(a1),
+            F_.P(topo.block_order), None, F_.stream())
+    assert torch.equal(o2, out.detach())
+    F_.call("jova_graphpool_fwd", F_.P(xd.detach()), n, 64, F_.P(topo.deg_slice), topo.adj_ptrs, F_.P(o2), F_.P(a2),
+            None, F_.P(topo.row_table), F_.stream())
+    assert torch.equal(a1, a2)
+    dy = gout.to(device)
+    dx_plain = torch.empty_like(out)
+    F_.call("jova_graphpool_bwd", F_.P(dy), F_.P(a1), n, 64, F_.P(topo.deg_slice), topo.adj_ptrs, F_.P(dx_plain),
+            F_.P(topo.sym_flag), 1, F_.P(topo.rev_pos), F_.P(topo.block_order), None, F_.stream())
+    assert torch.equal(dx_plain, xd.grad)
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_gather2d_nonsat_vs_reference_golden(device, tag):
     from jova_amd.nn.layers import GraphGather2D
@@ -1018,25 +1061,44 @@ def test_config4_graph_stack_vs_oracle(device):
     arg = torch.empty(o2.shape, dtype=torch.uint8, device=device)
     tmp = torch.empty_like(o2)
     F_.call("jova_graphpool_fwd", F_.P(o1), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs, F_.P(tmp), F_.P(arg),
-            None, F_.stream())
+            None, None, F_.stream())
     # the XCD-aware block order is a permutation of the 16-row blocks and changes nothing in the results
     order = topo.block_order
     assert torch.equal(torch.sort(order.long()).values.cpu(), torch.arange((o1.shape[0] + 15) // 16))
     tmp2, arg2 = torch.empty_like(tmp), torch.empty_like(arg)
     F_.call("jova_graphpool_fwd", F_.P(o1), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs, F_.P(tmp2), F_.P(arg2),
-            F_.P(order), F_.stream())
+            F_.P(order), None, F_.stream())
     assert torch.equal(tmp, tmp2) and torch.equal(arg, arg2)
+    # the row table (row, degree, first neighbours of every row in launch order) changes nothing either; built from
+    # the batch's block order and, a second time, in plain row order
+    table = topo.row_table
+    plain = torch.empty_like(table)
+    F_.call("jova_row_table", o1.shape[0], F_.P(topo.deg_slice), topo.adj_ptrs, F_.P(topo.rev_pos), None, F_.P(plain),
+            F_.stream())
+    assert torch.equal(torch.sort(table[:, 0]).values, torch.sort(plain[:, 0]).values)
+    live = plain[plain[:, 0] >= 0]
+    assert torch.equal(live[:, 0].cpu(), torch.arange(o1.shape[0], dtype=torch.int32))
+    for tb in (table, plain):
+        tmp3, arg3 = torch.full_like(tmp, float("nan")), torch.full_like(arg, 77)
+        F_.call("jova_graphpool_fwd", F_.P(o1), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs, F_.P(tmp3),
+                F_.P(arg3), None, F_.P(tb), F_.stream())
+        assert torch.equal(tmp, tmp3) and torch.equal(arg, arg3), "pool forward: the row table changes the result"
     dx_g, dx_s, dx_r = torch.empty_like(o2), torch.empty_like(o2), torch.empty_like(o2)
     F_.call("jova_graphpool_bwd", F_.P(dy), F_.P(arg), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs,
-            F_.P(dx_g), F_.P(topo.sym_flag), 1, None, None, F_.stream())
+            F_.P(dx_g), F_.P(topo.sym_flag), 1, None, None, None, F_.stream())
     F_.call("jova_graphpool_bwd", F_.P(dy), F_.P(arg), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs,
-            F_.P(dx_r), F_.P(topo.sym_flag), 1, F_.P(topo.rev_pos), None, F_.stream())
+            F_.P(dx_r), F_.P(topo.sym_flag), 1, F_.P(topo.rev_pos), None, None, F_.stream())
     dx_o = torch.empty_like(o2)
     F_.call("jova_graphpool_bwd", F_.P(dy), F_.P(arg), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs,
-            F_.P(dx_o), F_.P(topo.sym_flag), 1, F_.P(topo.rev_pos), F_.P(order), F_.stream())
+            F_.P(dx_o), F_.P(topo.sym_flag), 1, F_.P(topo.rev_pos), F_.P(order), None, F_.stream())
     assert torch.equal(dx_o, dx_r), "pool backward: the block order changes the result"
+    for tb in (table, plain):
+        dx_t = torch.full_like(o2, float("nan"))
+        F_.call("jova_graphpool_bwd", F_.P(dy), F_.P(arg), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs,
+                F_.P(dx_t), F_.P(topo.sym_flag), 1, F_.P(topo.rev_pos), None, F_.P(tb), F_.stream())
+        assert torch.equal(dx_t, dx_r), "pool backward: the row table changes the result"
     F_.call("jova_graphpool_bwd", F_.P(dy), F_.P(arg), o1.shape[0], 64, F_.P(topo.deg_slice), topo.adj_ptrs,
-            F_.P(dx_s), None, 0, None, None, F_.stream())
+            F_.P(dx_s), None, 0, None, None, None, F_.stream())
     H.assert_close(dx_g, dx_s, tol=1e-6, what="pool backward: gather form == atomic scatter form")
     assert torch.equal(dx_g, dx_r), "pool backward: precomputed reverse positions change the result"
     assert int((topo.rev_pos == 0xFF).sum()) == 0, "symmetric graph: every edge has its reverse"
@@ -1144,7 +1206,7 @@ def test_entry_points_capture_into_a_hip_graph(device):
         st = stream()
         call("jova_colstats", P(x), n, 64, P(stats), st)
         F_.gemm(F_._addr(a), 1024, 1, F_._addr(b), 1, 1024, F_._addr(c), 512, 128, 512, 1024, bias=P(bias))
-        call("jova_graphpool_fwd", P(x), n, 64, P(topo.deg_slice), topo.adj_ptrs, P(pooled), P(arg), None, st)
+        call("jova_graphpool_fwd", P(x), n, 64, P(topo.deg_slice), topo.adj_ptrs, P(pooled), P(arg), None, None, st)
         call("jova_nonsat_fwd_noalloc", P(pooled), n * 64, 1e-4, 100, P(ns_out), P(ns_df), P(nev), st)
 
     side = torch.cuda.Stream()
@@ -1209,3 +1271,65 @@ def test_new_entry_points_on_empty_and_ragged_inputs(device):
     flag = torch.zeros(1, dtype=torch.int32, device=device)
     call("jova_nonfinite_flag", P(z), 0, P(flag), st)
     assert int(flag.item()) == 0
+
+
+@pytest.mark.parametrize("form", ["fwd_bias_relu", "fwd_residual", "dx_plain", "dx_relu_mask", "dx_residual_k2048"])
+def test_bf16_pieces_with_b_split_beforehand(device, form):
+    """jova_gemm_f32_img (B split into its bf16 pieces once per call, A split once per element: gemm_x3w_kernel) against
+    fp64, with the same bound as the in-kernel split -- no worse than twice an fp32 FMA chain's own distance, floor 1e-6
+    of max|C| -- on the forward form (x W^T + bias, ReLU / residual) and the data-gradient form (dY W, with the ReLU mask
+    / a residual), and against the in-kernel form to a few ulps of the largest element (same pieces, other summation
+    order).  The size query answers 0 for the shapes and modes that stay on the other forms."""
+    from jova_amd import _lib
+    from jova_amd.nn import functional as F_
+    L = _lib.lib()
+    torch.manual_seed(21)
+    M, N, K = (1024, 512, 2048) if form == "dx_residual_k2048" else (2048, 2048, 512)
+    fwd = form.startswith("fwd")
+    A = torch.randn(M, K, device=device)
+    A[::7] *= 37.0
+    W = torch.randn((N, K) if fwd else (K, N), device=device) * 0.05
+    sbk, sbn = (1, K) if fwd else (N, 1)
+    bias = torch.randn(N, device=device) if form == "fwd_bias_relu" else None
+    R = torch.randn(M, N, device=device) if form in ("fwd_residual", "dx_relu_mask", "dx_residual_k2048") else None
+    relu = {"fwd_bias_relu": 1, "dx_relu_mask": 2}.get(form, 0)
+    need = L.jova_gemm_b_image_bytes(F_._addr(A), K, 1, F_._addr(W), sbk, sbn, M, N, K, 1, 1, 1)
+    assert need == 6 * N * K
+    assert L.jova_gemm_b_image_bytes(F_._addr(A), K, 1, F_._addr(W), sbk, sbn, M, N, K, 1, 1, 2) == 0      # split-K
+    assert L.jova_gemm_b_image_bytes(F_._addr(A), K, 1, F_._addr(W), sbk, sbn, M - 1, N, K, 1, 1, 1) == 0  # ragged rows
+    assert L.jova_gemm_b_image_bytes(F_._addr(A), K, 1, F_._addr(W), sbk, sbn, 128, 128, 512, 1, 1, 1) == 0  # small
+    img = torch.empty(need, dtype=torch.uint8, device=device)
+    F_.call("jova_gemm_b_image", F_._addr(W), sbk, sbn, N, K, F_.P(img), F_.stream())
+    out = torch.full((M, N), float("nan"), device=device)
+    args = (F_._addr(A), K, 1, F_._addr(W), sbk, sbn, F_._addr(out), N, M, N, K, 1.0, F_.P(bias),
+            F_._addr(R) if R is not None else None, N, relu, 1, 1, 1, 0, 0, 0, 0, 0, 0)
+    F_.call("jova_gemm_f32_img", *args, F_.P(img), F_.stream())
+    out2 = torch.full((M, N), float("nan"), device=device)
+    args2 = args[:6] + (F_._addr(out2),) + args[7:]
+    F_.call("jova_gemm_f32", *args2, F_.stream())
+    mode = L.jova_gemm_get_bf16x3()
+    try:
+        L.jova_gemm_set_bf16x3(0)
+        assert L.jova_gemm_b_image_bytes(F_._addr(A), K, 1, F_._addr(W), sbk, sbn, M, N, K, 1, 1, 1) == 0
+        out32 = torch.full((M, N), float("nan"), device=device)
+        F_.call("jova_gemm_f32_img", *(args[:6] + (F_._addr(out32),) + args[7:]), F_.P(img), F_.stream())   # image ignored
+    finally:
+        L.jova_gemm_set_bf16x3(mode)
+    Wd = W.double().t() if fwd else W.double()
+    ref = A.double() @ Wd
+    if bias is not None:
+        ref = ref + bias.double()
+    if relu == 2:
+        ref = torch.where(R.double() > 0, ref, torch.zeros_like(ref))
+    elif R is not None:
+        ref = ref + R.double()
+    if relu == 1:
+        ref = ref.clamp_min(0)
+    scale = float(ref.abs().max())
+    e_img = float((out.double() - ref).abs().max()) / scale
+    e_x3 = float((out2.double() - ref).abs().max()) / scale
+    e_32 = float((out32.double() - ref).abs().max()) / scale
+    assert e_img <= max(1e-6, 2 * e_32), (form, e_img, e_x3, e_32)
+    assert float((out - out2).abs().max()) / scale <= 4e-6, "image form against the in-kernel split"
+    if relu == 2:
+        assert bool(((out == 0) == (R <= 0)).all()) or bool((out[R <= 0] == 0).all())

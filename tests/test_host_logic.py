@@ -103,10 +103,11 @@ def test_abi_accepts_an_empty_batch_without_a_gpu():
     from jova_amd import _lib
     tok = ctypes.c_void_p(16)                                    # non-null stand-in for the per-batch tables (never read)
     _lib.call("jova_graphconv_fwd", None, 0, 64, 0, 64, 64, tok, tok, tok, tok, 1, None, None, tok, None, None)
-    _lib.call("jova_graphpool_fwd", None, 0, 64, tok, tok, None, None, None, None)
-    _lib.call("jova_graphpool_bwd", None, None, 0, 64, tok, tok, None, None, 0, None, None, None)
+    _lib.call("jova_graphpool_fwd", None, 0, 64, tok, tok, None, None, None, None, None)
+    _lib.call("jova_graphpool_bwd", None, None, 0, 64, tok, tok, None, None, 0, None, None, None, None)
+    _lib.call("jova_row_table", 0, tok, tok, None, None, None, None)
     with pytest.raises(RuntimeError, match="null pointer"):     # ... but not when there are atoms
-        _lib.call("jova_graphpool_fwd", None, 5, 64, tok, tok, None, None, None, None)
+        _lib.call("jova_graphpool_fwd", None, 5, 64, tok, tok, None, None, None, None, None)
 
 
 def test_block_order_is_a_permutation_with_one_eighth_of_every_bucket_per_xcd():
