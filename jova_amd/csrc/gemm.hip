@@ -857,38 +857,52 @@ gemm_bf16x3_kernel(X3Args xa) {
 // ------------------------------------------------------------------------------------------------ bf16 pieces, B split beforehand
 // The bf16-pieces product for a K-contiguous A and a B that many row tiles share (B = a weight matrix: the forward
 // products x W^T and the data gradients dY W of the FFN / projection layers).  PMC passes over the in-kernel form
-// (profiles/r03_pmc_x3_ffn1.json) show its limit: 7.9 VALU instructions per MFMA -- the split of 32 floats per lane and
-// k-tile, every element of A split by both waves that share its rows and every element of B by both waves that share its
-// columns AND by every one of the M / 128 row tiles -- as many VALU cycles as matrix cycles (434 M against 439 M), of which
-// only a quarter overlap.  Here
-//   * B is split ONCE per call by gemm_b_image_kernel into an image of bf16 fragments (6 bytes per element, laid out in
-//     the order the waves read it: [column tile][k32 block][k16 half][piece][32-column block][lane][8 bf16]), which the
-//     workgroups stream into LDS by global_load_lds_dwordx4, 24 KiB per k32 block, three stages, one barrier per block;
-//   * a wave owns 32 rows x 128 columns of the 128 x 128 tile, so its A rows are its own: they come straight from global
-//     memory into registers (64 contiguous bytes per lane and k32 block, requested one block ahead, no LDS, no barrier)
-//     and each element is split once -- 16 floats per lane and k32 block against 64 in the in-kernel form;
-//   * the k order inside a k32 block is permuted (lane half h, half-block s, j < 8: k = 16 h + 8 s + j), the same way for A
-//     and B, which only changes the summation order.
-// Vector memory is inline asm with hand-kept s_waitcnt vmcnt (requests retire in order): at the top of block s the
-// wave needs A(s) and B(s); issued after them is only B(s + 1) (6 requests).
+// (profiles/r03_pmc_x3_inkernel_ffn1.json) show its limit: 7.9 VALU instructions per MFMA -- the split of 32 floats per
+// lane and k-tile, every element of A split by both waves that share its rows and every element of B by both waves that
+// share its columns AND by every one of the M / 128 row tiles -- as many VALU cycles as matrix cycles (434 M against
+// 439 M), of which only a quarter overlap.  Here
+//   * B is split ONCE per call by gemm_b_image_kernel into an image of bf16 MFMA fragments (6 bytes per element, in the
+//     order the waves read it: [column tile][k32 block][piece][16-column block][lane][8 bf16]; lane l = column l & 15,
+//     k = 8 (l >> 4) + j), which the workgroups stream into LDS by global_load_lds_dwordx4, 24 KiB per k32 block, three
+//     stages (B is requested two blocks ahead), one barrier per block;
+//   * a wave owns 64 rows x 128 columns of the workgroup's 256 x 128 tile, so its A rows are its own: they come straight
+//     from global memory into registers (32 contiguous bytes per lane, row block and k32 block, requested one block
+//     ahead; no LDS, no barrier) and each element is split once -- 1.8 VALU instructions per MFMA-equivalent;
+//   * v_mfma_f32_16x16x32_bf16 (four 16-row blocks x eight 16-column blocks of accumulators per wave): one MFMA
+//     contracts the whole k32 block, so A travels and is split in ROW halves (blocks 0, 1 then 2, 3; its own registers,
+//     wait and split per half, which keeps the pieces of only one half alive beside the 128 accumulator registers).
+//     The chip holds a higher clock on this shape than on 32x32x16 under a matrix-dense load (MI355X_MICROARCH.md, DVFS
+//     item 7): measured here on the Davis step, 302 -> 278 us per FFN product (profiles/r03_x3w_forms.json, which also
+//     holds the phase stamps of the two earlier forms that led here: 128 x 128 tiles were bound by their ten
+//     vector-memory instructions per 48 MFMAs and their four-byte stores);
+//   * the image fragment is the MFMA's A operand and the activation piece its B operand (C^T = W x^T), so a lane ends
+//     up with four consecutive columns of one row; the epilogue turns each wave's block round in LDS and stores whole
+//     128-byte row segments.
+// Vector memory is inline asm with hand-kept s_waitcnt vmcnt (requests retire in order).  Order per block s: [top]
+// B(s+2) (6 requests), H0(s+1) (4) ... [middle] H1(s+1) (4); the top needs H0(s) and B(s): younger than H0(s) is only
+// H1(s) -> vmcnt(4); the middle needs H1(s): younger are B(s+2) and H0(s+1) -> vmcnt(10 | 4 | 0).
+// Rows past M (M % 256 == 128: the last row tile is half empty) read row M - 1 and are not stored.
 struct X3WArgs {
     GemmArgs g;
     const unsigned char* image;
     int ntm, ntn, nkb;
+    int vec_c;                  // C, the residual and the bias take 16-byte accesses
 };
 constexpr int X3W_STAGE = 24 * 1024;
-constexpr int X3W_NST = 3;
+#ifndef X3W_NG
+#define X3W_NG 4             // column tiles per group: an XCD's resident workgroups share X3W_NG tiles' images (L2)
+#endif
 
 __global__ void __launch_bounds__(256)
 gemm_b_image_kernel(const float* __restrict__ B, long long sbk, long long sbn, int N, int K, uint4* __restrict__ image) {
-    // one thread per (column, 8 k): unit u = (((nt * nkb + kb) * 2 + s) * 4 + cb) * 64 + lane
+    // one thread per (column, 8 k): unit u = ((nt * nkb + kb) * 8 + nb) * 64 + lane; the three pieces lie 8 KiB apart
     const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
     if (u >= (long long)N * K / 8) return;
-    const int lane = (int)(u & 63), cb = (int)((u >> 6) & 3), s = (int)((u >> 8) & 1);
+    const int lane = (int)(u & 63), nb = (int)((u >> 6) & 7);
     const long long blk = u >> 9;
     const int nkb = K / 32;
     const int kb = (int)(blk % nkb), nt = (int)(blk / nkb);
-    const int n = nt * 128 + cb * 32 + (lane & 31), k = kb * 32 + 16 * (lane >> 5) + 8 * s;
+    const int n = nt * 128 + nb * 16 + (lane & 15), k = kb * 32 + 8 * (lane >> 4);
     float lo[4], hi[4];
     if (sbk == 1) {
         const float4 x = *reinterpret_cast<const float4*>(B + (long long)n * sbn + k);
@@ -904,45 +918,83 @@ gemm_b_image_kernel(const float* __restrict__ B, long long sbk, long long sbn, i
     }
     bf16x8_t p[3];
     split8_regs(lo, hi, p);
-    uint4* dst = image + blk * (X3W_STAGE / 16) + ((s * 3) * 4 + cb) * 64 + lane;
+    uint4* dst = image + blk * (X3W_STAGE / 16) + nb * 64 + lane;
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) dst[pc * 4 * 64] = *reinterpret_cast<const uint4*>(&p[pc]);
+    for (int pc = 0; pc < 3; ++pc) dst[pc * 8 * 64] = *reinterpret_cast<const uint4*>(&p[pc]);
 }
+
+#ifdef X3W_PROFILE
+// dev-only build: cycles per phase of the block loop, summed per wave (512 workgroups from X3W_PROF_FIRST on): wait |
+// split | barrier | issue | products | whole loop | epilogue
+__device__ unsigned long long x3w_prof[512 * 4 * 8];
+extern "C" int jova_debug_x3w_prof(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(x3w_prof), sizeof(unsigned long long) * n);
+}
+#ifndef X3W_PROF_FIRST
+#define X3W_PROF_FIRST 1024
+#endif
+#define X3W_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define X3W_ADD(k, v) pf[k] += (v)
+#else
+#define X3W_STAMP(var)
+#define X3W_ADD(k, v)
+#endif
 
 #define X3W_GLOAD(dst, ptr, off) \
     asm volatile("global_load_dwordx4 %0, %1, off offset:" #off : "=v"(dst) : "v"(ptr) : "memory")
 
 __global__ void __launch_bounds__(256, 2)
 gemm_x3w_kernel(X3WArgs xa) {
-    __shared__ __attribute__((aligned(16))) unsigned char stages[X3W_NST * X3W_STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char stages[3 * X3W_STAGE];
     const GemmArgs& g = xa.g;
-    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, kg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int slot = blockIdx.x;               // workgroups b, b + 8, ... share an XCD: give each XCD a contiguous run of tiles
     {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = slot & 7, loc = slot >> 3;
         slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int mt = slot / xa.ntn, nt = slot - mt * xa.ntn;      // column tile fastest: neighbours share their A rows
-    const int m0 = mt * 128 + 32 * wave, n0 = nt * 128;
+    int mt, nt;                          // groups of X3W_NG column tiles; inside a group the column tile runs fastest
+    {
+        const int ng = X3W_NG > 0 ? X3W_NG : xa.ntn;
+        const int per_group = xa.ntm * ng, grp = slot / per_group, in = slot - grp * per_group;
+        const int width = min(ng, xa.ntn - grp * ng);
+        mt = in / width;
+        nt = grp * ng + (in - mt * width);
+    }
+    const int m0 = mt * 256 + 64 * wave, n0 = nt * 128;
     const int nkb = xa.nkb;
-    const float* ap = g.A + (long long)(m0 + i) * g.sam + 16 * h;
+    const float* ap0 = g.A + (long long)min(m0 + i, g.M - 1) * g.sam + 8 * kg;
+    const float* ap1 = g.A + (long long)min(m0 + 16 + i, g.M - 1) * g.sam + 8 * kg;
+    const float* ap2 = g.A + (long long)min(m0 + 32 + i, g.M - 1) * g.sam + 8 * kg;
+    const float* ap3 = g.A + (long long)min(m0 + 48 + i, g.M - 1) * g.sam + 8 * kg;
     const unsigned char* bp = xa.image + (long long)nt * nkb * X3W_STAGE + (wave * 6) * 1024 + lane * 16;
     const unsigned st0 = lds_addr(reinterpret_cast<const float*>(stages)) + (unsigned)(wave * 6) * 1024u;
 
-    f32x16 acc[4];
+    f32x4 acc[4][8];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+    for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+        for (int nb = 0; nb < 8; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 a0, a1, a2, a3;
-    auto issue_a = [&]() {
-        X3W_GLOAD(a0, ap, 0);
-        X3W_GLOAD(a1, ap, 16);
-        X3W_GLOAD(a2, ap, 32);
-        X3W_GLOAD(a3, ap, 48);
-        ap += 32;
+    // half 0: row blocks 0 (x) and 1 (y); half 1: row blocks 2 (u) and 3 (v); eight floats of the k32 block each
+    f32x4 x0, x1, y0, y1;
+    f32x4 u0, u1, v0, v1;
+    auto issue_h0 = [&]() {
+        X3W_GLOAD(x0, ap0, 0);
+        X3W_GLOAD(x1, ap0, 16);
+        X3W_GLOAD(y0, ap1, 0);
+        X3W_GLOAD(y1, ap1, 16);
+    };
+    auto issue_h1 = [&]() {
+        X3W_GLOAD(u0, ap2, 0);
+        X3W_GLOAD(u1, ap2, 16);
+        X3W_GLOAD(v0, ap3, 0);
+        X3W_GLOAD(v1, ap3, 16);
+        ap0 += 32;
+        ap1 += 32;
+        ap2 += 32;
+        ap3 += 32;
     };
     auto issue_b = [&](int stage) {
         const unsigned dst = st0 + (unsigned)stage * X3W_STAGE;
@@ -950,88 +1002,177 @@ gemm_x3w_kernel(X3WArgs xa) {
         for (int p = 0; p < 6; ++p) dma16(reinterpret_cast<const float*>(bp + p * 1024), dst + p * 1024);
         bp += X3W_STAGE;
     };
-    issue_a();
-    issue_b(0);
-    if (nkb > 1) issue_b(1);
-
-    int cur = 0, refill = 2;
-    // The registers the asm loads write must be the ones the split reads, with no copy in between that could run
-    // before the wait: the wait only READS a0..a3 (no new definition to allocate), scheduling barriers pin the split
-    // between the wait and the next loads (so the old and the new values never live together and the loop-carried
-    // value stays in place), and the last block is a second copy of the body (one wait statement per copy).
-    auto block = [&](int s, auto last_tag) {
-        constexpr bool LAST = decltype(last_tag)::value;
-        if (!LAST) asm volatile("s_waitcnt vmcnt(6)" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        bf16x8_t pa[2][3];
-        {
-            const float l0[4] = {a0[0], a0[1], a0[2], a0[3]}, h0[4] = {a1[0], a1[1], a1[2], a1[3]};
-            const float l1[4] = {a2[0], a2[1], a2[2], a2[3]}, h1[4] = {a3[0], a3[1], a3[2], a3[3]};
-            split8_regs(l0, h0, pa[0]);
-            split8_regs(l1, h1, pa[1]);
-        }
+    auto split_pair = [&](const f32x4& lo0, const f32x4& hi0, const f32x4& lo1, const f32x4& hi1, bf16x8_t (&pa)[2][3]) {
+        const float a[4] = {lo0[0], lo0[1], lo0[2], lo0[3]}, b[4] = {hi0[0], hi0[1], hi0[2], hi0[3]};
+        const float c[4] = {lo1[0], lo1[1], lo1[2], lo1[3]}, d[4] = {hi1[0], hi1[1], hi1[2], hi1[3]};
+        split8_regs(a, b, pa[0]);
+        split8_regs(c, d, pa[1]);
         // (the pieces are complete here: an empty asm that "rewrites" them keeps the split from sinking below the loads)
         asm volatile("" : "+v"(pa[0][0]), "+v"(pa[0][1]), "+v"(pa[0][2]), "+v"(pa[1][0]), "+v"(pa[1][1]), "+v"(pa[1][2])::"memory");
+    };
+    // the 96 products of one row half: small terms first (A.h B.l | A.m B.m, A.h B.m | A.l B.h, A.m B.h, A.h B.h)
+    auto products = [&](const unsigned char* sb, const bf16x8_t (&pa)[2][3], int mb0) {
+        bf16x8_t bf[4];
+#pragma unroll
+        for (int pb = 2; pb >= 0; --pb) {
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    bf[nb] = *reinterpret_cast<const bf16x8_t*>(sb + (pb * 8 + 4 * nh + nb) * 1024);
+#pragma unroll
+                for (int pa_i = 2 - pb; pa_i >= 0; --pa_i)
+#pragma unroll
+                    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb)
+                            acc[mb0 + mh][4 * nh + nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                bf[nb], pa[mh][pa_i], acc[mb0 + mh][4 * nh + nb], 0, 0, 0);
+            }
+        }
+    };
+
+    issue_b(0);
+    if (nkb > 1) issue_b(1);
+    issue_h0();
+    issue_h1();
+
+    int cur = 0, refill = 2;
+#ifdef X3W_PROFILE
+    unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long pf_begin = __builtin_amdgcn_s_memtime();
+#endif
+    // NEXT: block s + 1 exists (A is requested one block ahead); B2: block s + 2 exists (B two blocks ahead)
+    auto block = [&](auto next_tag, auto b2_tag) {
+        constexpr bool NEXT = decltype(next_tag)::value, B2 = decltype(b2_tag)::value;
+        bf16x8_t pa[2][3];
+        X3W_STAMP(p0);
+        asm volatile("s_waitcnt vmcnt(4)" ::"v"(x0), "v"(x1), "v"(y0), "v"(y1) : "memory");
         __builtin_amdgcn_sched_barrier(0);
+        X3W_STAMP(p1);
+        split_pair(x0, x1, y0, y1, pa);
+        __builtin_amdgcn_sched_barrier(0);
+        X3W_STAMP(p2);
         __builtin_amdgcn_s_barrier();    // B(s) of every wave has landed; every wave is past its reads of stage `refill`
         asm volatile("" ::: "memory");
-        if (!LAST) issue_a();
-        if (!LAST && s + 2 < nkb) issue_b(refill);
+        X3W_STAMP(p3);
+        if (B2) issue_b(refill);
+        if (NEXT) issue_h0();
+        X3W_STAMP(p4);
         const unsigned char* sb = stages + cur * X3W_STAGE + lane * 16;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8_t bf[4];
-            // small terms first: A.h B.l | A.m B.m, A.h B.m | A.l B.h, A.m B.h, A.h B.h
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) bf[cb] = *reinterpret_cast<const bf16x8_t*>(sb + ((s2 * 3 + 2) * 4 + cb) * 1024);
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2][0], bf[cb], acc[cb], 0, 0, 0);
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) bf[cb] = *reinterpret_cast<const bf16x8_t*>(sb + ((s2 * 3 + 1) * 4 + cb) * 1024);
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2][1], bf[cb], acc[cb], 0, 0, 0);
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2][0], bf[cb], acc[cb], 0, 0, 0);
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) bf[cb] = *reinterpret_cast<const bf16x8_t*>(sb + ((s2 * 3 + 0) * 4 + cb) * 1024);
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2][2], bf[cb], acc[cb], 0, 0, 0);
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2][1], bf[cb], acc[cb], 0, 0, 0);
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2][0], bf[cb], acc[cb], 0, 0, 0);
-        }
-        cur = cur == X3W_NST - 1 ? 0 : cur + 1;
-        refill = refill == X3W_NST - 1 ? 0 : refill + 1;
+        products(sb, pa, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef X3W_PROFILE
+        asm volatile("s_nop 0" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]), "+v"(acc[0][7]), "+v"(acc[1][7]), "+v"(acc[2][7]), "+v"(acc[3][7]));
+#endif
+        X3W_STAMP(p5);
+        if (B2) asm volatile("s_waitcnt vmcnt(10)" ::"v"(u0), "v"(u1), "v"(v0), "v"(v1) : "memory");
+        else if (NEXT) asm volatile("s_waitcnt vmcnt(4)" ::"v"(u0), "v"(u1), "v"(v0), "v"(v1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::"v"(u0), "v"(u1), "v"(v0), "v"(v1) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        X3W_STAMP(p6);
+        split_pair(u0, u1, v0, v1, pa);
+        __builtin_amdgcn_sched_barrier(0);
+        X3W_STAMP(p7);
+        if (NEXT) issue_h1();
+        X3W_STAMP(p8);
+        products(sb, pa, 2);
+        cur = cur == 2 ? 0 : cur + 1;
+        refill = refill == 2 ? 0 : refill + 1;
+#ifdef X3W_PROFILE
+        asm volatile("s_nop 0" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]), "+v"(acc[0][7]), "+v"(acc[1][7]), "+v"(acc[2][7]), "+v"(acc[3][7]));
+        const unsigned long long p9 = __builtin_amdgcn_s_memtime();
+        X3W_ADD(0, (p1 - p0) + (p6 - p5)); X3W_ADD(1, (p2 - p1) + (p7 - p6)); X3W_ADD(2, p3 - p2); X3W_ADD(3, (p4 - p3) + (p8 - p7));
+        X3W_ADD(4, (p5 - p4) + (p9 - p8));
+#endif
     };
-    for (int s = 0; s + 1 < nkb; ++s) block(s, std::false_type());
-    block(nkb - 1, std::true_type());
+    for (int s = 0; s + 2 < nkb; ++s) block(std::true_type(), std::true_type());
+    if (nkb > 1) block(std::true_type(), std::false_type());
+    block(std::false_type(), std::false_type());
 
-    // epilogue: alpha, bias, residual / ReLU mask, ReLU (as the whole-tile branch of gemm_f32_fast_kernel)
+#ifdef X3W_PROFILE
+    const unsigned long long pf_loop_end = __builtin_amdgcn_s_memtime();
+#endif
+    // epilogue: acc[mb][nb] holds row m0 + 16 mb + i, columns n0 + 16 nb + 4 kg + (0..3): four consecutive columns.
+    // Stored as they lie, an instruction would write 32 bytes to each of 32 rows (stamped on the 32x32x16 form: 55 000
+    // cycles per tile, a third of the tile's time); each wave turns a 32 x 128 block round in its own 16 KiB of the (now
+    // idle) stage memory instead -- 16-byte chunk c of row r at chunk c ^ sw(r), conflict-free for the ds_write_b128
+    // down a column and the ds_read_b128 along rows -- and stores whole 128-byte row segments (47 000 cycles: what is
+    // left is the store path itself, about 7 bytes per cycle and CU; without its stores the launch takes 285 us
+    // instead of 360).
+    __syncthreads();                     // every wave is past its last reads of the stages
+    float* const reg = reinterpret_cast<float*>(stages) + wave * 4096;
+    const bool vec = xa.vec_c != 0;
+    auto sw = [](int r) { return (r & 7) ^ (((r >> 1) & 1) << 3); };
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        const int n = n0 + 32 * cb + i;
-        const float bias = g.bias ? g.bias[n] : 0.f;
-        float* crow = g.C + n;
-        float rv[16];
+    for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + mfma32_row(r, lane);
-            rv[r] = g.R ? g.R[(long long)m * g.ldr + n] : 0.f;
-        }
+        for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + mfma32_row(r, lane);
-            float v = g.alpha * acc[cb][r] + bias;
-            if (g.relu == 2) v = rv[r] > 0.f ? v : 0.f;
-            else v += rv[r];
-            if (g.relu == 1) v = fmaxf(v, 0.f);
-            crow[(long long)m * g.ldc] = v;
+            for (int nb = 0; nb < 8; ++nb) {
+                const int r = 16 * mh + i, c = 4 * nb + kg;
+                *reinterpret_cast<f32x4*>(reg + (r * 32 + (c ^ sw(r))) * 4) = acc[2 * rb + mh][nb];
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (lane >> 3) + 8 * j, m = m0 + 32 * rb + r;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = (lane & 7) + 8 * k, n = n0 + 4 * c;
+                const f32x4 t = *reinterpret_cast<const f32x4*>(reg + (r * 32 + (c ^ sw(r))) * 4);
+                if (m >= g.M) continue;
+                float o[4], rv[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
+                if (g.bias) {
+                    if (vec) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(g.bias + n);
+                        bs[0] = b4.x; bs[1] = b4.y; bs[2] = b4.z; bs[3] = b4.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bs[e] = g.bias[n + e];
+                    }
+                }
+                if (g.R) {
+                    const float* rrow = g.R + (long long)m * g.ldr + n;
+                    if (vec) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(rrow);
+                        rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rv[e] = rrow[e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = g.alpha * t[e] + bs[e];
+                    if (g.relu == 2) v = rv[e] > 0.f ? v : 0.f;
+                    else v += rv[e];
+                    if (g.relu == 1) v = fmaxf(v, 0.f);
+                    o[e] = v;
+                }
+                float* cp = g.C + (long long)m * g.ldc + n;
+#ifdef X3W_NO_STORE
+                if (o[0] != 12345.678f) continue;        // dev-only: how long the launch takes without its stores
+#endif
+                if (vec) *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cp[e] = o[e];
+                }
+            }
         }
     }
+#ifdef X3W_PROFILE
+    if (lane == 0 && blockIdx.x >= X3W_PROF_FIRST && blockIdx.x < X3W_PROF_FIRST + 512) {
+        unsigned long long* d = x3w_prof + ((size_t)(blockIdx.x - X3W_PROF_FIRST) * 4 + wave) * 8;
+        for (int k = 0; k < 5; ++k) d[k] = pf[k];
+        d[5] = pf_loop_end - pf_begin;
+        d[6] = __builtin_amdgcn_s_memtime() - pf_loop_end;
+        d[7] = pf_begin;
+    }
+#endif
 }
 #undef X3W_GLOAD
+
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -1120,9 +1261,11 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
         X3WArgs xw;
         xw.g = g;
         xw.image = (const unsigned char*)b_image;
-        xw.ntm = M / 128;
+        xw.ntm = cdiv(M, 256);
         xw.ntn = N / 128;
         xw.nkb = K / 32;
+        xw.vec_c = aligned16(C) && ldc % 4 == 0 && (!residual || (aligned16(residual) && ldr % 4 == 0)) &&
+                   (!bias || aligned16(bias));
         const long long nwg = (long long)xw.ntm * xw.ntn;
         JOVA_CHECK_ARG(nwg < (1ll << 31), "gemm: too many tiles");
         hipLaunchKernelGGL(gemm_x3w_kernel, dim3((unsigned)nwg), dim3(256), 0, s, xw);
