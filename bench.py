@@ -133,11 +133,12 @@ def launch_ranks(n):
     return subprocess.call(cmd)
 
 
-def measured_traffic():
-    """HBM-side bytes per launch of the probed GEMM from the committed PMC passes (profiles/r02_pmc_ffn1.json, else r01:
-    FETCH_SIZE / WRITE_SIZE collected in separate rocprofv3 --pmc runs of tools/one_gemm.py, gfx950 corrections applied
-    as MI355X_MICROARCH.md prescribes).  It is quoted for the S = 279 launch those passes ran, not re-measured here."""
-    for name in ("r02_pmc_ffn1.json", "r01_pmc_ffn1.json"):
+def measured_traffic(names=("r02_pmc_ffn1.json", "r01_pmc_ffn1.json")):
+    """HBM-side bytes per launch of the probed GEMM from the committed PMC passes (profiles/r03_pmc_x3w_ffn1.json for the
+    bf16-pieces kernel, r02_pmc_ffn1.json for the fp32 MFMA kernel: FETCH_SIZE / WRITE_SIZE collected in separate rocprofv3
+    --pmc runs of tools/one_gemm.py, gfx950 corrections applied as MI355X_MICROARCH.md prescribes).  It is quoted for the
+    S = 279 launch those passes ran, not re-measured here."""
+    for name in names:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return int(json.load(f)["traffic_bytes_per_launch"])
@@ -219,7 +220,7 @@ def graph_stress(device, reps=20, full=True, row_order_lines=True):
     res = []
 
     pmc = {}
-    for name in ("r01_pmc_graph.json", "r02_pmc_graph.json"):       # later rounds override per kernel
+    for name in ("r01_pmc_graph.json", "r02_pmc_graph.json", "r03_pmc_graph.json"):       # later rounds override per kernel
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pmc.update(json.load(f)["kernels"])
@@ -535,13 +536,20 @@ def main():
                         avg_us=round(ms_f * 1e3 / max(len(probe_f), 1), 1),
                         note="the probed launch in the fp32_mfma_only run: fp32 MFMA (v_mfma_f32_32x32x2_f32), algorithmic flops")
     if x3_was >= 2:
-        roofline = dict(kernel="gemm_f32_fast_kernel<K-contig,K-contig,X3: fp32 from bf16 pieces> " + shape_txt, bound="mfma",
+        roofline = dict(kernel="gemm_x3w_kernel: fp32 from bf16 pieces, W split beforehand " + shape_txt, bound="mfma",
                         achieved=round(6.0 * tfl, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(6.0 * tfl / MFMA_BF16_PEAK_TFLOPS, 4), algorithmic_tflops=round(tfl, 2),
-                        traffic=None, launches=len(probe), avg_us=round(ms * 1e3 / max(len(probe), 1), 1),
-                        note="six v_mfma_f32_32x32x16_bf16 piece products per fp32 product: achieved = 6 x algorithmic "
+                        traffic=measured_traffic(("r03_pmc_x3w_ffn1.json",)),
+                        traffic_note="NOT re-measured in this run: bytes per launch of the S=279 launch that "
+                                     "profiles/r03_pmc_x3w_ffn1.json profiled (2*FETCH_SIZE + WRITE_SIZE, separate --pmc "
+                                     "passes; algorithmic bytes of that launch 372.0e6: x, the 6-byte-per-element image of "
+                                     "W, bias, the output); this run's launches average S*B = %d tokens" % int(tokens_per_step),
+                        launches=len(probe), avg_us=round(ms * 1e3 / max(len(probe), 1), 1),
+                        note="six v_mfma_f32_16x16x32_bf16 piece products per fp32 product: achieved = 6 x algorithmic "
                              "flops / time against the dense bf16 matrix peak; algorithmic_tflops = 2MNK / time "
-                             "(fp32-equivalent).  The same launch on the fp32 matrix pipe: roofline_fp32_mfma_only")
+                             "(fp32-equivalent); the probe brackets the product's launch only (the image of W is a "
+                             "5-us launch of its own in front of it).  The same launch on the fp32 matrix pipe: "
+                             "roofline_fp32_mfma_only")
     else:
         roofline = dict(roofline_f32, achieved=round(tfl, 2), frac=round(tfl / MFMA_F32_PEAK_TFLOPS, 4), launches=len(probe),
                         avg_us=round(ms * 1e3 / max(len(probe), 1), 1), note="the probed launch in the default run")

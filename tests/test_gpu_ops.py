@@ -1273,18 +1273,22 @@ def test_new_entry_points_on_empty_and_ragged_inputs(device):
     assert int(flag.item()) == 0
 
 
-@pytest.mark.parametrize("form", ["fwd_bias_relu", "fwd_residual", "dx_plain", "dx_relu_mask", "dx_residual_k2048"])
+@pytest.mark.parametrize("form", ["fwd_bias_relu", "fwd_residual", "dx_plain", "dx_relu_mask", "dx_residual_k2048",
+                                  "fwd_k32", "fwd_k64", "dx_k96"])
 def test_bf16_pieces_with_b_split_beforehand(device, form):
     """jova_gemm_f32_img (B split into its bf16 pieces once per call, A split once per element: gemm_x3w_kernel) against
     fp64, with the same bound as the in-kernel split -- no worse than twice an fp32 FMA chain's own distance, floor 1e-6
     of max|C| -- on the forward form (x W^T + bias, ReLU / residual) and the data-gradient form (dY W, with the ReLU mask
-    / a residual), and against the in-kernel form to a few ulps of the largest element (same pieces, other summation
-    order).  The size query answers 0 for the shapes and modes that stay on the other forms."""
+    / a residual), with one to 64 k32 blocks and a half-empty last row tile, and against the in-kernel form to a few ulps
+    of the largest element (same pieces, other summation order).  The size query answers 0 for the shapes and modes that
+    stay on the other forms."""
     from jova_amd import _lib
     from jova_amd.nn import functional as F_
     L = _lib.lib()
     torch.manual_seed(21)
     M, N, K = (1152, 512, 2048) if form == "dx_residual_k2048" else (2048, 2048, 512)     # (1152: a half-empty last row tile)
+    if form in ("fwd_k32", "fwd_k64", "dx_k96"):             # one, two and three k32 blocks: the peeled ends of the block loop
+        M, N, K = 16384 + 128, 2048, {"fwd_k32": 32, "fwd_k64": 64, "dx_k96": 96}[form]
     fwd = form.startswith("fwd")
     A = torch.randn(M, K, device=device)
     A[::7] *= 37.0
