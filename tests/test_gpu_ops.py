@@ -1274,7 +1274,7 @@ def test_new_entry_points_on_empty_and_ragged_inputs(device):
 
 
 @pytest.mark.parametrize("form", ["fwd_bias_relu", "fwd_residual", "dx_plain", "dx_relu_mask", "dx_residual_k2048",
-                                  "fwd_k32", "fwd_k64", "dx_k96"])
+                                  "fwd_k32", "fwd_k64", "dx_k96", "fwd_unaligned_c"])
 def test_bf16_pieces_with_b_split_beforehand(device, form):
     """jova_gemm_f32_img (B split into its bf16 pieces once per call, A split once per element: gemm_x3w_kernel) against
     fp64, with the same bound as the in-kernel split -- no worse than twice an fp32 FMA chain's own distance, floor 1e-6
@@ -1294,7 +1294,7 @@ def test_bf16_pieces_with_b_split_beforehand(device, form):
     A[::7] *= 37.0
     W = torch.randn((N, K) if fwd else (K, N), device=device) * 0.05
     sbk, sbn = (1, K) if fwd else (N, 1)
-    bias = torch.randn(N, device=device) if form == "fwd_bias_relu" else None
+    bias = torch.randn(N, device=device) if form in ("fwd_bias_relu", "fwd_unaligned_c") else None
     R = torch.randn(M, N, device=device) if form in ("fwd_residual", "dx_relu_mask", "dx_residual_k2048") else None
     relu = {"fwd_bias_relu": 1, "dx_relu_mask": 2}.get(form, 0)
     need = L.jova_gemm_b_image_bytes(F_._addr(A), K, 1, F_._addr(W), sbk, sbn, M, N, K, 1, 1, 1)
@@ -1307,7 +1307,13 @@ def test_bf16_pieces_with_b_split_beforehand(device, form):
     out = torch.full((M, N), float("nan"), device=device)
     args = (F_._addr(A), K, 1, F_._addr(W), sbk, sbn, F_._addr(out), N, M, N, K, 1.0, F_.P(bias),
             F_._addr(R) if R is not None else None, N, relu, 1, 1, 1, 0, 0, 0, 0, 0, 0)
-    F_.call("jova_gemm_f32_img", *args, F_.P(img), F_.stream())
+    if form == "fwd_unaligned_c":                            # C four bytes off a 16-byte boundary, rows of N + 1 floats:
+        buf = torch.full((M * (N + 1) + 1,), float("nan"), device=device)      # the scalar-store path of the epilogue
+        F_.call("jova_gemm_f32_img", *(args[:6] + (F_._addr(buf, 1), N + 1) + args[8:]), F_.P(img), F_.stream())
+        out = buf[1:].view(M, N + 1)[:, :N].contiguous()
+        assert bool(torch.isnan(buf[1:].view(M, N + 1)[:, N]).all()) and bool(torch.isnan(buf[0])), "stores outside C"
+    else:
+        F_.call("jova_gemm_f32_img", *args, F_.P(img), F_.stream())
     out2 = torch.full((M, N), float("nan"), device=device)
     args2 = args[:6] + (F_._addr(out2),) + args[7:]
     F_.call("jova_gemm_f32", *args2, F_.stream())
