@@ -1102,10 +1102,8 @@ gemm_x3w_kernel(X3WArgs xa) {
     // instead of 360).
     __syncthreads();                     // every wave is past its last reads of the stages
     float* const reg = reinterpret_cast<float*>(stages) + wave * 4096;
-    const bool vec = xa.vec_c != 0;
     auto sw = [](int r) { return (r & 7) ^ (((r >> 1) & 1) << 3); };
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
+    auto to_lds = [&](int rb) {
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -1113,53 +1111,77 @@ gemm_x3w_kernel(X3WArgs xa) {
                 const int r = 16 * mh + i, c = 4 * nb + kg;
                 *reinterpret_cast<f32x4*>(reg + (r * 32 + (c ^ sw(r))) * 4) = acc[2 * rb + mh][nb];
             }
+    };
+    // Straight-line form (16-byte accesses): the bias and the residual / mask values of a block are requested BEFORE its
+    // stores and nothing is loaded between two stores.  Requests retire in order, so a load behind a store waits for the
+    // store's acknowledgement: with a bias load in front of every store (the first version) the 32 stores of a tile ran
+    // one round trip each, 47 000 cycles per tile.
+    auto epilogue_vec = [&](auto bias_tag, auto r_tag) {
+        constexpr bool HB = decltype(bias_tag)::value, HR = decltype(r_tag)::value;
+        const int c0 = lane & 7, r0 = lane >> 3;
+        f32x4 bs[4], rv[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = (lane >> 3) + 8 * j, m = m0 + 32 * rb + r;
+        for (int k = 0; k < 4; ++k)
+            bs[k] = HB ? *reinterpret_cast<const f32x4*>(g.bias + n0 + 4 * (c0 + 8 * k)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto load_r = [&](int rb, int jh) {              // the values of two row groups (8 of the block's 16 chunks)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = (lane & 7) + 8 * k, n = n0 + 4 * c;
+            for (int j = 0; j < 2; ++j) {
+                const int m = min(m0 + 32 * rb + r0 + 8 * (2 * jh + j), g.M - 1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    rv[4 * j + k] = *reinterpret_cast<const f32x4*>(g.R + (long long)m * g.ldr + n0 + 4 * (c0 + 8 * k));
+            }
+        };
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            to_lds(rb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (HR && (j & 1) == 0) load_r(rb, j >> 1);      // (waits for the stores before it: four drains per tile, not 32)
+                const int r = r0 + 8 * j, m = m0 + 32 * rb + r;
+                f32x4 o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = c0 + 8 * k;
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(reg + (r * 32 + (c ^ sw(r))) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = g.alpha * t[e] + bs[k][e];
+                        if (HR) v = g.relu == 2 ? (rv[4 * (j & 1) + k][e] > 0.f ? v : 0.f) : v + rv[4 * (j & 1) + k][e];
+                        o[k][e] = g.relu == 1 ? fmaxf(v, 0.f) : v;
+                    }
+                }
+                if (m < g.M) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)      // (non-temporal: 232 MB of output pass through, FFN linear1 279 -> 274 us)
+                        __builtin_nontemporal_store(o[k], reinterpret_cast<f32x4*>(g.C + (long long)m * g.ldc + n0 + 4 * (c0 + 8 * k)));
+                }
+            }
+        }
+    };
+    if (xa.vec_c) {
+        if (g.bias && g.R) epilogue_vec(std::true_type(), std::true_type());
+        else if (g.bias) epilogue_vec(std::true_type(), std::false_type());
+        else if (g.R) epilogue_vec(std::false_type(), std::true_type());
+        else epilogue_vec(std::false_type(), std::false_type());
+    } else {                              // C, residual or bias off a 16-byte boundary: element by element
+#pragma unroll                            // (rb must be a constant: a runtime index would put the accumulators in scratch)
+        for (int rb = 0; rb < 2; ++rb) {
+            to_lds(rb);
+#pragma unroll 1
+            for (int jk = 0; jk < 16; ++jk) {
+                const int j = jk >> 2, k = jk & 3;
+                const int r = (lane >> 3) + 8 * j, m = m0 + 32 * rb + r, c = (lane & 7) + 8 * k, n = n0 + 4 * c;
                 const f32x4 t = *reinterpret_cast<const f32x4*>(reg + (r * 32 + (c ^ sw(r))) * 4);
                 if (m >= g.M) continue;
-                float o[4], rv[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
-                if (g.bias) {
-                    if (vec) {
-                        const float4 b4 = *reinterpret_cast<const float4*>(g.bias + n);
-                        bs[0] = b4.x; bs[1] = b4.y; bs[2] = b4.z; bs[3] = b4.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) bs[e] = g.bias[n + e];
-                    }
-                }
-                if (g.R) {
-                    const float* rrow = g.R + (long long)m * g.ldr + n;
-                    if (vec) {
-                        const float4 r4 = *reinterpret_cast<const float4*>(rrow);
-                        rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) rv[e] = rrow[e];
-                    }
-                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = g.alpha * t[e] + bs[e];
-                    if (g.relu == 2) v = rv[e] > 0.f ? v : 0.f;
-                    else v += rv[e];
+                    float v = g.alpha * t[e] + (g.bias ? g.bias[n + e] : 0.f);
+                    const float rr = g.R ? g.R[(long long)m * g.ldr + n + e] : 0.f;
+                    if (g.relu == 2) v = rr > 0.f ? v : 0.f;
+                    else v += rr;
                     if (g.relu == 1) v = fmaxf(v, 0.f);
-                    o[e] = v;
-                }
-                float* cp = g.C + (long long)m * g.ldc + n;
-#ifdef X3W_NO_STORE
-                if (o[0] != 12345.678f) continue;        // dev-only: how long the launch takes without its stores
-#endif
-                if (vec) {                       // (non-temporal: 232 MB of output pass through, FFN linear1 279 -> 274 us)
-                    f32x4 ov = {o[0], o[1], o[2], o[3]};
-                    __builtin_nontemporal_store(ov, reinterpret_cast<f32x4*>(cp));
-                }
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) cp[e] = o[e];
+                    g.C[(long long)m * g.ldc + n + e] = v;
                 }
             }
         }
