@@ -697,11 +697,15 @@ __device__ __forceinline__ void split4(const float v[4], bf16x4& h, bf16x4& m, b
     }
 }
 
-// LDS: [buffer][piece][row][k16 slab], 48-byte rows (the 16-byte fragment reads of 16 lanes cover all banks once); the
-// two 16-byte halves of a row trade places on rows 16..31 mod 32, which halves the bank conflicts of the transposing
-// store of a row-contiguous operand (lanes on rows 2 apart, 96 bytes)
+// LDS: [buffer][piece][row][k16 slab], 48-byte rows; the two 16-byte halves of a row trade places by bits 2 ^ 3 ^ 4 of
+// the row: the fragment reads (ds_read_b128's non-contiguous lane groups) are conflict-free (round 3; until then the
+// halves traded places on rows 16..31 and the reads were two-way, like the transposing stores of a row-contiguous
+// operand, which still are in this kernel: a wave stores one k block, so only every other 8-byte slot of the 128-byte
+// window is ever used.  The thread map that cures that -- 4 row pairs x 4 k blocks per 16 lanes, gemm_bf16x3_dw_kernel --
+// measured slower HERE: 5.15 against 4.87 ms per step with every weight gradient on this kernel; its global loads then
+// touch four k rows per instruction.)
 constexpr int XLD16 = 24;
-__device__ __forceinline__ int x3_half(int row, int half) { return (half ^ ((row >> 4) & 1)) * 8; }
+__device__ __forceinline__ int x3_half(int row, int half) { return (half ^ (((row >> 2) ^ (row >> 3) ^ (row >> 4)) & 1)) * 8; }
 
 template <bool KC>
 struct X3Operand {                      // one 128 x 16 operand slab: global -> registers -> three bf16 images in LDS
@@ -851,6 +855,143 @@ gemm_bf16x3_kernel(X3Args xa) {
         atomicAdd(&s_cs[2 * (tid & 63) + 1], cs[1]);
         __syncthreads();
         if (tid < 128) atomicAdd(&g.csum[m0 + tid], s_cs[tid]);
+    }
+}
+
+// Weight gradients (both operands row-contiguous: dW = dY^T X) on 256 x 256 workgroup tiles, eight waves of 64 x 128.
+// The register-staged kernel above splits every element of dY once per 128-column tile of dW and every element of X once
+// per 128-row tile: per k16 slab a thread splits 16 elements for its wave's 24 MFMAs, as many VALU cycles as matrix
+// cycles (the same balance the PMC passes showed for the in-kernel forward form).  With 256 x 256 tiles a thread still
+// splits 16 elements per slab but its wave has 48 MFMAs for them: half the split work per product.  Same LDS images,
+// same staging (thread = row pair x 4 k, transposed in registers), same piece order as gemm_bf16x3_kernel<false, false>;
+// one workgroup per CU (147 KiB of LDS), the contraction split over 256 / tiles workgroups, partial sums added with
+// float atomics (the dW contract: C accumulates); the bias gradient is summed from the fp32 registers before the split.
+// LDS image: [buffer][piece][row][16 k], 48-byte rows; the 8-byte chunk q (k = 4 q .. 4 q + 3) of row r sits at chunk
+// q ^ dw_swz(r) (dw_swz is 0 or 2: the two 16-byte halves of a row trade places; the order of k inside a fragment must be
+// the same in every lane, an MFMA pairs every A row with every B column).  PMC on the first version (the images and the
+// thread map of gemm_bf16x3_kernel) read SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE: the transposing 8-byte stores
+// of 16 consecutive row pairs (one k block per wave: only every other 8-byte slot of the 128-byte window is ever used)
+// and the 16-byte fragment reads of ds_read_b128's non-contiguous lane groups were both two-way.  Here a 16-lane group
+// stages 4 row pairs x 4 k blocks and the halves trade places by bits 2 ^ 3 ^ 4 of the row: both conflict-free (checked
+// with the bank rules of MI355X_MICROARCH.md, then with the counter: 0).
+__device__ __forceinline__ int dw_swz(int row) { return (((row >> 2) ^ (row >> 3) ^ (row >> 4)) & 1) << 1; }
+
+__global__ void __launch_bounds__(512, 1)
+gemm_bf16x3_dw_kernel(X3Args xa) {
+    __shared__ __attribute__((aligned(16))) __bf16 sA[2][3][256][XLD16];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[2][3][256][XLD16];
+    __shared__ float s_cs[256];
+    const GemmArgs& g = xa.g;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int tiles = xa.ntm * xa.ntn;
+    int slot = blockIdx.x;               // workgroups b, b + 8, ... share an XCD: give each XCD a contiguous run of work items
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = slot & 7, loc = slot >> 3;
+        slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tile = slot % tiles, part = slot / tiles;
+    const int m0 = (tile / xa.ntn) * 256, n0 = (tile % xa.ntn) * 256;
+    const int kt0 = part * xa.per, nk = min(xa.per, xa.nk_total - kt0);
+    const int kbase = kt0 * XBK, ns = 2 * nk;               // k16 slabs of this part (even)
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 128;
+    const bool do_cs = g.csum != nullptr && n0 == 0;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float cs[2] = {0.f, 0.f};
+    if (tid < 256) s_cs[tid] = 0.f;
+    const long long lda = g.sak, ldb = g.sbk;
+    const int rp = tid >> 2, kq = tid & 3;                  // this thread stages rows 2 rp, 2 rp + 1 at k = 4 kq .. 4 kq + 3
+    float ra[2][8], rb[2][8];                               // two slabs in flight (slot = slab & 1)
+    auto load_slab = [&](float (&r)[8], const float* base, long long ld, int row0, int k0) {
+        const float* p = base + (long long)(k0 + 4 * kq) * ld + row0 + 2 * rp;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) *reinterpret_cast<float2*>(&r[2 * kk]) = *reinterpret_cast<const float2*>(p + kk * ld);
+    };
+    auto store_slab = [&](const float (&r)[8], __bf16 (*sp)[256][XLD16]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 2 * rp + j;
+            const float v[4] = {r[j], r[2 + j], r[4 + j], r[6 + j]};
+            bf16x4 p0, p1, p2;
+            split4(v, p0, p1, p2);
+            const int c = 4 * (kq ^ dw_swz(row));
+            *reinterpret_cast<bf16x4*>(&sp[0][row][c]) = p0;
+            *reinterpret_cast<bf16x4*>(&sp[1][row][c]) = p1;
+            *reinterpret_cast<bf16x4*>(&sp[2][row][c]) = p2;
+        }
+    };
+#define DW_LOAD(SL, s_)                                                                       \
+    do {                                                                                      \
+        load_slab(ra[SL], g.A, lda, m0, kbase + 16 * (s_));                                   \
+        load_slab(rb[SL], g.B, ldb, n0, kbase + 16 * (s_));                                   \
+    } while (0)
+#define DW_STORE(SL, BUF, s_)                                                                 \
+    do {                                                                                      \
+        const bool live = do_cs && (s_) < ns;                                                 \
+        cs[0] += live ? (ra[SL][0] + ra[SL][2]) + (ra[SL][4] + ra[SL][6]) : 0.f;              \
+        cs[1] += live ? (ra[SL][1] + ra[SL][3]) + (ra[SL][5] + ra[SL][7]) : 0.f;              \
+        store_slab(ra[SL], sA[BUF]);                                                          \
+        store_slab(rb[SL], sB[BUF]);                                                          \
+    } while (0)
+    // One slab: the split + store of slab s+1 and the request for slab s+3 sit in the same basic block as the MFMAs of
+    // slab s, one barrier per slab.  Fragments: all three pieces of the wave's two A row blocks, the four B column blocks
+    // one piece at a time (small terms first: A.h B.l | A.m B.m, A.h B.m | A.l B.h, A.m B.h, A.h B.h).
+#define DW_STEP(CUR, s_)                                                                      \
+    do {                                                                                      \
+        DW_STORE(1 - CUR, 1 - CUR, (s_) + 1);                                                 \
+        DW_LOAD(1 - CUR, min((s_) + 3, ns - 1));                                              \
+        bf16x8 fa[3][2];                                                                      \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p)                                         \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                     \
+                fa[p][t] = *reinterpret_cast<const bf16x8*>(&sA[CUR][p][wm + 32 * t + i][8 * (h ^ (dw_swz(i) >> 1))]); \
+        _Pragma("unroll") for (int pb = 2; pb >= 0; --pb) {                                   \
+            bf16x8 fb[4];                                                                     \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                     \
+                fb[t] = *reinterpret_cast<const bf16x8*>(&sB[CUR][pb][wn + 32 * t + i][8 * (h ^ (dw_swz(i) >> 1))]); \
+            _Pragma("unroll") for (int pa = 2 - pb; pa >= 0; --pa)                            \
+                _Pragma("unroll") for (int a = 0; a < 2; ++a)                                 \
+                    _Pragma("unroll") for (int b = 0; b < 4; ++b)                             \
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][a], fb[b], acc[a][b], 0, 0, 0); \
+        }                                                                                     \
+        __syncthreads();                                                                      \
+    } while (0)
+    DW_LOAD(0, 0);
+    DW_LOAD(1, 1);
+    DW_STORE(0, 0, 0);
+    DW_LOAD(0, min(2, ns - 1));
+    __syncthreads();
+    for (int s_i = 0; s_i < ns; s_i += 2) {
+        DW_STEP(0, s_i);
+        DW_STEP(1, s_i + 1);
+    }
+#undef DW_LOAD
+#undef DW_STORE
+#undef DW_STEP
+    const bool first = part == 0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int n = n0 + wn + 32 * b + i;
+            const float bias = (g.bias && first) ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * a + mfma32_row(r, lane);
+                float v = g.alpha * acc[a][b][r] + bias;
+                if (g.R && first) v += g.R[(long long)m * g.ldr + n];
+                atomicAdd(&g.C[(long long)m * g.ldc + n], v);
+            }
+        }
+    if (do_cs) {                                 // thread (row pair, k block) carried rows 2 rp, 2 rp + 1
+        atomicAdd(&s_cs[2 * rp], cs[0]);
+        atomicAdd(&s_cs[2 * rp + 1], cs[1]);
+        __syncthreads();
+        if (tid < 256) atomicAdd(&g.csum[m0 + tid], s_cs[tid]);
     }
 }
 
@@ -1299,6 +1440,31 @@ static int gemm_impl(const float* A, int64_t sam, int64_t sak, const float* B, i
     }
     // dW (both operands row-contiguous) on the register-staged kernel (262-290 us against 292-332 us), dX (A K-contiguous)
     // on the LDS-DMA form of the persistent kernel (338 us against 364 us on average): kernel trace of the Davis step
+    // weight gradients with at least eight 256 x 256 tiles (the FFN and QKV layers): the big-tile form, the contraction
+    // split over about one workgroup per CU
+    static int x3_dw_big = -1;
+    if (x3_dw_big < 0) x3_dw_big = getenv("JOVA_GEMM_NO_DW256") ? 0 : 1;
+    if (x3_want && x3_dw_big && !x3_old && !a_kc && !b_kc && splitk > 1 && !relu && M % 256 == 0 && N % 256 == 0 &&
+        (long long)(M / 256) * (N / 256) >= 8 && (long long)(M / 256) * (N / 256) <= 256 && K / XBK >= 64) {
+        X3Args xa;
+        xa.g = g;
+        xa.ntm = M / 256;
+        xa.ntn = N / 256;
+        xa.nk_total = K / XBK;
+        const int tiles = xa.ntm * xa.ntn;
+        int parts = 256 / tiles;
+        if (parts > xa.nk_total / 8) parts = xa.nk_total / 8;            // at least 8 k32 tiles per part
+        if (parts < 1) parts = 1;
+        xa.per = (xa.nk_total + parts - 1) / parts;
+        xa.parts = (xa.nk_total + xa.per - 1) / xa.per;
+        if (csum) {
+            xa.g.csum = csum;
+            if (csum_done) *csum_done = true;
+        }
+        hipLaunchKernelGGL(gemm_bf16x3_dw_kernel, dim3((unsigned)(tiles * xa.parts)), dim3(512), 0, s, xa);
+        JOVA_CHECK_LAUNCH("gemm_bf16x3_dw");
+        return JOVA_OK;
+    }
     if (x3_want && (x3_old || !a_kc)) {
         X3Args xa;
         xa.g = g;

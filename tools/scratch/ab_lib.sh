@@ -1,5 +1,5 @@
 #!/bin/bash
-# bench A/B of the default library against tools/scratch/libs/lib_<name>.so, twice each, one box: ab_lib.sh <name>
+# bench A/B of the default library against tools/scratch/libs/lib_<name>.so, twice each, one box: ab_lib.sh <name> ...
 set -u
 O=gpurun_out/r3y; mkdir -p $O
 for rep in 1 2; do
