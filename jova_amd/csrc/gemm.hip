@@ -876,6 +876,20 @@ gemm_bf16x3_kernel(X3Args xa) {
 // with the bank rules of MI355X_MICROARCH.md, then with the counter: 0).
 __device__ __forceinline__ int dw_swz(int row) { return (((row >> 2) ^ (row >> 3) ^ (row >> 4)) & 1) << 1; }
 
+#ifdef DW_CLOCK
+// lab build (-DDW_CLOCK, tools/scratch/dw_time.py): per workgroup, shader cycles (s_memtime) and 100 MHz ticks
+// (s_memrealtime) from entry to the end of the slab loop, and the ticks at entry / loop begin / loop end / exit.  What it
+// showed on the FFN gradient (S = 221): 4 409 cycles per slab against 3 072 of matrix-pipe time, at 1.66 GHz on normally
+// distributed operands and 2.29 GHz on all-zero ones (same instruction stream: the launch is power-limited).
+__device__ unsigned long long dw_clk[1024 * 4];
+__device__ unsigned long long dw_clk2[1024 * 4];
+extern "C" int jova_debug_dw_clk(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dw_clk), sizeof(unsigned long long) * n);
+}
+extern "C" int jova_debug_dw_clk2(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dw_clk2), sizeof(unsigned long long) * n);
+}
+#endif
 __global__ void __launch_bounds__(512, 1)
 gemm_bf16x3_dw_kernel(X3Args xa) {
     __shared__ __attribute__((aligned(16))) __bf16 sA[2][3][256][XLD16];
@@ -895,6 +909,9 @@ gemm_bf16x3_dw_kernel(X3Args xa) {
     const int kbase = kt0 * XBK, ns = 2 * nk;               // k16 slabs of this part (even)
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 128;
     const bool do_cs = g.csum != nullptr && n0 == 0;
+#ifdef DW_CLOCK
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     f32x16 acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -965,6 +982,9 @@ gemm_bf16x3_dw_kernel(X3Args xa) {
     DW_STORE(0, 0, 0);
     DW_LOAD(0, min(2, ns - 1));
     __syncthreads();
+#ifdef DW_CLOCK
+    const unsigned long long clk_r1 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int s_i = 0; s_i < ns; s_i += 2) {
         DW_STEP(0, s_i);
         DW_STEP(1, s_i + 1);
@@ -972,6 +992,16 @@ gemm_bf16x3_dw_kernel(X3Args xa) {
 #undef DW_LOAD
 #undef DW_STORE
 #undef DW_STEP
+#ifdef DW_CLOCK
+    const unsigned long long clk_r2 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && blockIdx.x < 1024) {
+        unsigned long long* d = dw_clk + 4 * blockIdx.x;
+        d[0] = __builtin_amdgcn_s_memtime() - clk_t0;
+        d[1] = clk_r2 - clk_r0;
+        d[2] = (unsigned long long)ns;
+        d[3] = clk_r0;
+    }
+#endif
     const bool first = part == 0;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -993,6 +1023,13 @@ gemm_bf16x3_dw_kernel(X3Args xa) {
         __syncthreads();
         if (tid < 256) atomicAdd(&g.csum[m0 + tid], s_cs[tid]);
     }
+#ifdef DW_CLOCK
+    __syncthreads();
+    if (tid == 0 && blockIdx.x < 1024) {
+        unsigned long long* d = dw_clk2 + 4 * blockIdx.x;
+        d[0] = clk_r0; d[1] = clk_r1; d[2] = clk_r2; d[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ bf16 pieces, B split beforehand
